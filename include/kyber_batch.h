@@ -1,0 +1,118 @@
+/*
+ * kyber_batch.h -- C-ABI batch entry points of libkyber_hip.so, the MI355X
+ * (gfx950) engine for the round-3 Kyber KEM hot path.
+ *
+ * Plain C linkage, plain pointers and sizes.  Instance i of a batch lives at
+ * base + i * <BYTES> in every array (dense, no padding), exactly the objects
+ * the reference's three API functions take one at a time:
+ *
+ *   keypair  replaces  int crypto_kem_keypair(uint8_t *pk, uint8_t *sk)           ref/kem.c:23, ref/api.h:16,39,62
+ *   enc      replaces  int crypto_kem_enc(uint8_t *ct, uint8_t *ss, const uint8_t *pk)   ref/kem.c:51, ref/api.h:17,40,63
+ *   dec      replaces  int crypto_kem_dec(uint8_t *ss, const uint8_t *ct, const uint8_t *sk)  ref/kem.c:94, ref/api.h:18,41,64
+ *
+ * The reference draws its entropy through a link-time randombytes()
+ * (ref/randombytes.h:7) in a fixed order: d (ref/indcpa.c:215), z
+ * (ref/kem.c:32), m0 (ref/kem.c:59).  The batch calls take those draws as an
+ * explicit `coins` array so that results are reproducible bit for bit;
+ * coins == NULL makes the library draw them from randombytes() itself.
+ *
+ * Return value: 0 on success (the reference's functions always return 0,
+ * ref/kem.c:33,74,126); negative on a HIP/runtime error or bad argument, the
+ * only failure class this layer adds:
+ *   KYBER_HIP_EINVAL (-1) bad parameter set or NULL pointer
+ *   KYBER_HIP_ENOSYS (-2) parameter set not built into this library
+ *   KYBER_HIP_EHIP   (-3) a HIP runtime call failed (kyber_hip_last_error())
+ * Decapsulation failure is not an error: ss is then the pseudo-random value
+ * the reference defines (implicit rejection, ref/kem.c:116-125).
+ *
+ * All sizes of one object are multiples of 16 bytes; device pointers passed
+ * to the *_dev calls must be 16-byte aligned.
+ */
+#ifndef KYBER_BATCH_H
+#define KYBER_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KYBER_HIP_EINVAL (-1)
+#define KYBER_HIP_ENOSYS (-2)
+#define KYBER_HIP_EHIP   (-3)
+
+/* parameter-set selector for the generic entry points: k in {2,3,4}
+ * (ref/params.h:4-8 KYBER_K), nineties = 1 for the -90s sets (KYBER_90S) */
+
+/* object sizes, = ref/params.h:63-66 / ref/api.h:6-9,29-32,52-55; 0 for a bad k */
+size_t kyber_hip_pk_bytes(int k);
+size_t kyber_hip_sk_bytes(int k);
+size_t kyber_hip_ct_bytes(int k);
+#define KYBER_HIP_SS_BYTES 32
+#define KYBER_HIP_KEYPAIR_COINS 64 /* d || z  */
+#define KYBER_HIP_ENC_COINS 32     /* m0      */
+
+/* ---- host-memory batch calls (north_star's kyber_batch_{keypair,enc,dec}(n, ...)) ----
+ * Buffers are ordinary host memory; the call copies in, runs on the current
+ * HIP device and copies out before returning. */
+int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins /* n*64 or NULL */);
+int kyber_batch_enc(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins /* n*32 or NULL */);
+int kyber_batch_dec(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);
+
+/* ---- device-memory batch calls ----
+ * Every pointer is device memory on the current HIP device (coins must not be
+ * NULL); work is enqueued on `stream` (a hipStream_t passed as void*, NULL =
+ * default stream) and the call returns without synchronising.  The internal
+ * workspace is per device and grows on demand; calls on one device must not
+ * overlap in time. */
+int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins, void *stream);
+int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, void *stream);
+int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
+
+/* per-set spellings, e.g. kyber768_batch_enc(n, ct, ss, pk, coins) */
+#define KYBER_HIP_DECLARE_SET(NAME)                                                                         \
+  int NAME##_batch_keypair(size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins);                       \
+  int NAME##_batch_enc(size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins);        \
+  int NAME##_batch_dec(size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);
+KYBER_HIP_DECLARE_SET(kyber512)
+KYBER_HIP_DECLARE_SET(kyber768)
+KYBER_HIP_DECLARE_SET(kyber1024)
+KYBER_HIP_DECLARE_SET(kyber512_90s)
+KYBER_HIP_DECLARE_SET(kyber768_90s)
+KYBER_HIP_DECLARE_SET(kyber1024_90s)
+
+/* ---- batched polynomial arithmetic on device memory (BASELINE.json config 2) ----
+ * polys are dense int16_t[256] records (the reference's `poly`, ref/poly.h:11-13).
+ *   ntt        in place, = poly_ntt            ref/poly.c:244-248 (ntt + Barrett)
+ *   invntt     in place, = poly_invntt_tomont  ref/poly.c:259-262
+ *   basemul    r = a o b, = poly_basemul_montgomery  ref/poly.c:273-280
+ *   mul_fused  r = invntt_tomont(poly_reduce(poly_ntt(a) o poly_ntt(b))) in one kernel */
+int kyber_batch_poly_ntt_dev(size_t npoly, int16_t *r, void *stream);
+int kyber_batch_poly_invntt_dev(size_t npoly, int16_t *r, void *stream);
+int kyber_batch_poly_basemul_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
+int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
+
+/* ---- stage-level device entry points (parity tests of single kernels) ----
+ * gen_matrix: mat[i][e][256] int16, e = row*k + col of A (transposed = 0) or
+ * A^T (transposed = 1) expanded from seeds[i][32].        ref/indcpa.c:164-192 */
+int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, const uint8_t *seeds, int transposed, void *stream);
+
+/* ---- housekeeping ---- */
+/* instances processed per internal pass (workspace sizing); 0 restores the default */
+int kyber_hip_set_chunk(size_t instances);
+/* release the current device's workspace */
+int kyber_hip_release(void);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char *kyber_hip_last_error(void);
+
+/* Entropy hook, same contract as the reference's (ref/randombytes.h:7).  The
+ * library ships a weak default backed by getrandom(2); a program that defines
+ * its own randombytes() overrides it at link time, as the reference's test
+ * harnesses do (ref/test_vectors.c:41). */
+void randombytes(uint8_t *out, size_t outlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

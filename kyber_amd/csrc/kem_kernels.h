@@ -1,0 +1,579 @@
+// kem_kernels.h -- the batched KEM as a short pipeline of gfx950 kernels.
+//
+// Two work decompositions alternate, each the natural one for its stage:
+//
+//   sponge layout  one work-item per Keccak sponge (64 sponges per wavefront,
+//                  state in VGPRs): FO hashes (one sponge per KEM instance),
+//                  SHAKE128 matrix expansion with rejection sampling (one per
+//                  matrix entry) and the SHAKE256 PRF (one per noise poly).
+//   poly layout    32 work-items per polynomial, 8 instances per 256-thread
+//                  workgroup, polynomials in LDS: NTT, base multiplication,
+//                  inverse NTT, noise, compression and packing.
+//
+// Between stages the per-instance intermediates (expanded matrix, PRF bytes,
+// 128 bytes of seeds/flags) live in a device workspace laid out so that both
+// producer and consumer touch it with contiguous, 16-byte-aligned accesses.
+//
+// Reference call trees restated: ref/kem.c:23-127, ref/indcpa.c:164-329.
+#pragma once
+#include "keccak.h"
+#include "poly.h"
+
+namespace ky {
+
+template <int K_>
+struct Par {
+  static constexpr int K = K_;
+  static constexpr int ETA1 = (K_ == 2) ? 3 : 2;          // ref/params.h:42-54
+  static constexpr int DU = (K_ == 4) ? 11 : 10;
+  static constexpr int DV = (K_ == 4) ? 5 : 4;
+  static constexpr int PVB = 384 * K_;                     // polyvec bytes
+  static constexpr int PKB = PVB + 32;                     // ref/params.h:63
+  static constexpr int SKB = 2 * PVB + 96;                 // ref/params.h:65
+  static constexpr int CTB = 32 * (DU * K_ + DV);          // ref/params.h:66
+  static constexpr int UB = 32 * DU;                       // one compressed u poly
+  static constexpr int NMAT = K_ * K_;
+  static constexpr int PRF_STRIDE = 64 * ETA1;             // bytes per PRF job slot (>= 128)
+};
+
+// workspace "small" record, 128 bytes per instance
+//   enc/dec: [0,32) m   [32,64) Kbar   [64,96) r (coins)   [96,100) fail flag
+//   keypair: [0,32) rho [32,64) sigma
+constexpr int SMALL = 128;
+constexpr int G_INST = 8;  // instances per poly-layout workgroup
+
+// ------------------------------------------------------------------ small hashes
+// sha3_256 of 32 bytes already in registers
+__device__ __forceinline__ void sha3_256_32(u64p (&A)[25], const u64p (&in)[4]) {
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = in[w];
+  A[4].lo = 0x06;
+  A[16].hi = 0x80000000u;
+  keccak_f1600(A);
+}
+// sha3_512 of 64 bytes (two 32-byte halves in registers) -> A[0..7]
+__device__ __forceinline__ void sha3_512_64(u64p (&A)[25], const u64p (&a)[4], const u64p (&b)[4]) {
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) { A[w] = a[w]; A[4 + w] = b[w]; }
+  A[8].lo = 0x06;
+  A[8].hi = 0x80000000u;
+  keccak_f1600(A);
+}
+// shake256(64 bytes) -> first 32 bytes in A[0..3]           (kdf, ref/symmetric.h:56)
+__device__ __forceinline__ void shake256_64(u64p (&A)[25], const u64p (&a)[4], const u64p (&b)[4]) {
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) { A[w] = a[w]; A[4 + w] = b[w]; }
+  A[8].lo = 0x1F;
+  A[16].hi = 0x80000000u;
+  keccak_f1600(A);
+}
+
+__device__ __forceinline__ void ld32B(const uint8_t* p, u64p (&v)[4]) {
+  uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
+  v[0] = u64p{a.x, a.y}; v[1] = u64p{a.z, a.w}; v[2] = u64p{b.x, b.y}; v[3] = u64p{b.z, b.w};
+}
+__device__ __forceinline__ void st32B(uint8_t* p, const u64p& a, const u64p& b, const u64p& c, const u64p& d) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(a.lo, a.hi, b.lo, b.hi);
+  *reinterpret_cast<uint4*>(p + 16) = make_uint4(c.lo, c.hi, d.lo, d.hi);
+}
+
+// ------------------------------------------------------------------ FO hashes
+// keypair, before: (rho, sigma) = G(d).                        ref/indcpa.c:215-216
+__global__ void __launch_bounds__(256) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p d[4], A[25];
+  ld32B(coins + (size_t)i * 64, d);
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = d[w];
+  A[4].lo = 0x06;
+  A[8].hi = 0x80000000u;
+  keccak_f1600(A);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32B(s, A[0], A[1], A[2], A[3]);
+  st32B(s + 32, A[4], A[5], A[6], A[7]);
+}
+
+// keypair, after: sk tail = H(pk) || z.                          ref/kem.c:30-32
+template <class P>
+__global__ void __launch_bounds__(256) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                 uint8_t* __restrict__ sk) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25], z[4];
+  keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
+  uint8_t* tail = sk + (size_t)i * P::SKB + 2 * P::PVB + 32;
+  st32B(tail, A[0], A[1], A[2], A[3]);
+  ld32B(coins + (size_t)i * 64 + 32, z);
+  st32B(tail + 32, z[0], z[1], z[2], z[3]);
+}
+
+// encaps, before: m = H(m0); (Kbar, r) = G(m || H(pk)).         ref/kem.c:59-65
+template <class P>
+__global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                 uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25], m[4], h[4];
+  ld32B(coins + (size_t)i * 32, m);
+  sha3_256_32(A, m);
+#pragma unroll
+  for (int w = 0; w < 4; w++) m[w] = A[w];
+  keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
+#pragma unroll
+  for (int w = 0; w < 4; w++) h[w] = A[w];
+  sha3_512_64(A, m, h);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32B(s, m[0], m[1], m[2], m[3]);
+  st32B(s + 32, A[0], A[1], A[2], A[3]);
+  st32B(s + 64, A[4], A[5], A[6], A[7]);
+}
+
+// decaps, middle: (Kbar', r') = G(m' || H(pk) from sk).          ref/kem.c:109-111
+template <class P>
+__global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restrict__ sk, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25], m[4], h[4];
+  uint8_t* s = small + (size_t)i * SMALL;
+  ld32B(s, m);
+  ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 32, h);
+  sha3_512_64(A, m, h);
+  st32B(s + 32, A[0], A[1], A[2], A[3]);
+  st32B(s + 64, A[4], A[5], A[6], A[7]);
+}
+
+// encaps/decaps, after: ss = KDF(Kbar-or-z || H(ct)).            ref/kem.c:71-73, :116-125
+template <class P, bool DEC>
+__global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+                                              const uint8_t* __restrict__ sk, uint8_t* __restrict__ ss) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25], kb[4], h[4];
+  keccak_absorb_words<136, 0x06, P::CTB>(A, ct + (size_t)i * P::CTB);
+#pragma unroll
+  for (int w = 0; w < 4; w++) h[w] = A[w];
+  const uint8_t* s = small + (size_t)i * SMALL;
+  ld32B(s + 32, kb);
+  if constexpr (DEC) {
+    // constant-time select as ref/verify.c:40-47: kb ^= mask & (kb ^ z)
+    u64p z[4];
+    ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 64, z);
+    uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      kb[w].lo ^= mask & (kb[w].lo ^ z[w].lo);
+      kb[w].hi ^= mask & (kb[w].hi ^ z[w].hi);
+    }
+  }
+  shake256_64(A, kb, h);
+  st32B(ss + (size_t)i * 32, A[0], A[1], A[2], A[3]);
+}
+
+// ------------------------------------------------------------------ SHAKE256 PRF
+// One work-item per (nonce, instance); jobs are nonce-major so a wavefront is
+// uniform in the output length.  Writes the raw PRF bytes; the centred
+// binomial map is applied by the consumer in poly layout.
+// ref/symmetric-shake.c:43-51 + ref/poly.c:208-232 (prf part).
+template <class P>
+__global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+                                             int seed_off, uint8_t* __restrict__ prf) {
+  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)n * njobs_per_inst) return;
+  int nonce = (int)(gid / n), inst = (int)(gid % n);
+  u64p A[25], key[4];
+  ld32B(small + (size_t)inst * SMALL + seed_off, key);
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = key[w];
+  A[4].lo = (uint32_t)nonce | 0x1F00u;
+  A[16].hi = 0x80000000u;
+  keccak_f1600(A);
+  uint8_t* out = prf + ((size_t)inst * njobs_per_inst + nonce) * P::PRF_STRIDE;
+#pragma unroll
+  for (int w = 0; w < 16; w += 2) *reinterpret_cast<uint4*>(out + 8 * w) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
+  if constexpr (P::ETA1 == 3) {
+    if (nonce < n_eta1) {  // 192 bytes: 17 words of block one, 7 of block two (ref/fips202.c:729-733)
+      u64p w16 = A[16];
+      keccak_f1600(A);
+      *reinterpret_cast<uint4*>(out + 128) = make_uint4(w16.lo, w16.hi, A[0].lo, A[0].hi);
+#pragma unroll
+      for (int w = 1; w < 7; w += 2)
+        *reinterpret_cast<uint4*>(out + 136 + 8 * (w - 1) + 8) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ matrix expansion
+// One work-item per matrix entry: SHAKE128(rho || x || y), squeeze 168-byte
+// blocks, parse 3-byte groups into two 12-bit candidates, keep those < q until
+// 256 are found (ref/indcpa.c:124-145, :164-192; the reference's block
+// refill-and-carry is the same as this continuous stream parse because
+// 168 % 3 == 0).
+//
+// Per block each lane appends its accepted values to a private row of an LDS
+// staging tile ("always store, advance only on accept": no divergent branch),
+// then the wavefront drains the tile row by row so that every global store is
+// a contiguous run of one polynomial.  Lanes that still miss coefficients after
+// three blocks (P ~ 0.8 % each) keep the whole wavefront squeezing.
+constexpr int STAGE_DW = 57;  // dwords per lane: 1 carry slot + 112 candidates + 1 spill
+
+template <int BITOFF>
+__device__ __forceinline__ uint32_t field12(const uint32_t (&H)[42]) {
+  constexpr int k = BITOFF >> 5, s = BITOFF & 31;
+  if constexpr (s == 0) return H[k] & 0xFFFu;
+  else if constexpr (s == 20) return H[k] >> 20;
+  else if constexpr (s < 20) return __builtin_amdgcn_ubfe(H[k], s, 12);
+  else return __builtin_amdgcn_alignbit(H[k + 1], H[k], s) & 0xFFFu;
+}
+
+template <int G>
+__device__ __forceinline__ void parse_group(const uint32_t (&H)[42], uint16_t*& wp) {
+  uint32_t d1 = field12<24 * G>(H), d2 = field12<24 * G + 12>(H);
+  *wp = (uint16_t)d1;
+  wp += (d1 < (uint32_t)Q) ? 1 : 0;
+  *wp = (uint16_t)d2;
+  wp += (d2 < (uint32_t)Q) ? 1 : 0;
+}
+template <int G0, int G1>
+__device__ __forceinline__ void parse_range(const uint32_t (&H)[42], uint16_t*& wp) {
+  if constexpr (G0 < G1) {
+    parse_group<G0>(H, wp);
+    parse_range<G0 + 1, G1>(H, wp);
+  }
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                       int transposed, int16_t* __restrict__ mat) {
+  __shared__ uint32_t stage[4][64 * STAGE_DW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long job0 = (long)blockIdx.x * 256 + wave * 64;  // first job of this wavefront
+  const long job = job0 + lane;
+  const bool valid = job < njobs;
+  const long jc = valid ? job : (long)njobs - 1;
+  const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
+  const int i = e / P::K, j = e % P::K;
+  const uint32_t x = transposed ? i : j, y = transposed ? j : i;  // ref/indcpa.c:173-176
+
+  u64p A[25], seed[4];
+  ld32B(rho + (size_t)inst * rho_stride, seed);
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = seed[w];
+  A[4].lo = x | y << 8 | 0x1F0000u;  // rho || x || y || pad    ref/symmetric-shake.c:25-29
+  A[20].hi = 0x80000000u;
+
+  uint32_t* row = stage[wave] + lane * STAGE_DW;
+  uint32_t* tile = stage[wave];
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
+  int ctr = valid ? 0 : 256;
+
+  while (__any(ctr < 256)) {
+    keccak_f1600(A);
+    uint32_t H[42];
+#pragma unroll
+    for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
+    // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
+    uint16_t* wp0 = reinterpret_cast<uint16_t*>(row) + (ctr & 1);
+    uint16_t* wp = wp0;
+    parse_range<0, 56>(H, wp);
+    const int c0 = ctr;
+    const int c1 = c0 + (int)(wp - wp0);
+    // drain: polynomial of lane p gets dwords [c0>>1, (min(c1,256)+1)>>1)
+#pragma unroll 1
+    for (int p = 0; p < 64; p++) {
+      const int pc0 = __builtin_amdgcn_readlane(c0, p);
+      if (pc0 >= 256) continue;
+      int pc1 = __builtin_amdgcn_readlane(c1, p);
+      pc1 = pc1 < 256 ? pc1 : 256;
+      const int d0 = pc0 >> 1, nd = ((pc1 + 1) >> 1) - d0;
+      if (lane < nd) out32[(job0 + p) * 128 + d0 + lane] = tile[p * STAGE_DW + lane];
+    }
+    // carry an unpaired last coefficient to slot 0 for the next block
+    if (c0 < 256 && (c1 & 1)) {
+      uint16_t* h = reinterpret_cast<uint16_t*>(row);
+      h[0] = h[(c0 & 1) + (c1 - c0) - 1];
+    }
+    ctr = c0 < 256 ? c1 : c0;
+  }
+}
+
+// ------------------------------------------------------------------ poly-layout helpers
+struct Grp {
+  int g, t;  // group in workgroup (0..7), work-item in group (0..31)
+};
+__device__ __forceinline__ Grp grp() { return Grp{(int)threadIdx.x >> 5, (int)threadIdx.x & 31}; }
+
+__device__ __forceinline__ void ld_coef8(const int16_t* p, int t, int (&c)[8]) {
+  unpack8(*reinterpret_cast<const uint4*>(p + 8 * t), c);
+}
+
+// ------------------------------------------------------------------ keypair arithmetic
+// ref/indcpa.c:220-238: s,e <- CBD(PRF); s^,e^ = NTT; t^ = A s^ (tomont) + e^;
+// pk = tobytes(t^) || rho ; sk = tobytes(s^) (|| pk copy, ref/kem.c:28-29)
+template <class P>
+__global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
+                                                  const uint8_t* __restrict__ prf, uint8_t* __restrict__ pk,
+                                                  uint8_t* __restrict__ sk) {
+  constexpr int K = P::K;
+  __shared__ __attribute__((aligned(16))) int16_t se[G_INST][2 * K][256];  // s^ then e^
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+
+  for (int q = w.g; q < G_INST * 2 * K; q += 8) {
+    const int li = q / (2 * K), v = q % (2 * K);
+    const int gi = min(inst0 + li, n - 1);
+    int c[8];
+    cbd_contig<P::ETA1>(prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE, w.t, c);
+    KY_GSYNC();
+    lds_put_contig(wk[w.g], w.t, c);
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], w.t, c);
+    lds_put_contig(se[li][v], w.t, c);
+    if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
+      uint32_t w0, w1, w2;
+      tobytes12(c, w0, w1, w2);
+      uint32_t* o = reinterpret_cast<uint32_t*>(sk + (size_t)gi * P::SKB + 384 * v) + 3 * w.t;
+      o[0] = w0; o[1] = w1; o[2] = w2;
+    }
+  }
+  KY_GSYNC();
+  for (int q = w.g; q < G_INST * K; q += 8) {
+    const int li = q / K, i = q % K;
+    const int gi = min(inst0 + li, n - 1);
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      ld_coef8(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
+      lds_get_contig(se[li][j], w.t, b);
+      basemul_acc(acc, a, b, w.t);
+    }
+    lds_get_contig(se[li][K + i], w.t, b);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int r = barrett(acc[k]);                  // ref/polyvec.c:200
+      r = mont_reduce(r * 1353);                // poly_tomont, ref/poly.c:290-296
+      acc[k] = barrett(r + b[k]);               // + e^, reduce   ref/indcpa.c:234-235
+    }
+    if (inst0 + li < n) {
+      uint32_t w0, w1, w2;
+      tobytes12(acc, w0, w1, w2);
+      uint32_t* o = reinterpret_cast<uint32_t*>(pk + (size_t)gi * P::PKB + 384 * i) + 3 * w.t;
+      o[0] = w0; o[1] = w1; o[2] = w2;
+      uint32_t* o2 = reinterpret_cast<uint32_t*>(sk + (size_t)gi * P::SKB + P::PVB + 384 * i) + 3 * w.t;
+      o2[0] = w0; o2[1] = w1; o2[2] = w2;
+    }
+  }
+  // rho -> pk tail and its copy inside sk
+  if (threadIdx.x < G_INST * 8) {
+    const int li = threadIdx.x >> 3, wd = threadIdx.x & 7;
+    if (inst0 + li < n) {
+      const size_t gi = inst0 + li;
+      uint32_t r = reinterpret_cast<const uint32_t*>(small + gi * SMALL)[wd];
+      reinterpret_cast<uint32_t*>(pk + gi * P::PKB + P::PVB)[wd] = r;
+      reinterpret_cast<uint32_t*>(sk + gi * P::SKB + 2 * P::PVB)[wd] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ encryption arithmetic
+// ref/indcpa.c:268-295.  CMP = false: write the ciphertext.  CMP = true
+// (decapsulation's re-encryption, ref/kem.c:114-116): compare with the given
+// ciphertext instead and raise the instance's fail flag on any difference.
+template <class P, bool CMP>
+__global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
+                                                   uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
+                                                   const uint8_t* __restrict__ prf, uint8_t* __restrict__ ct) {
+  constexpr int K = P::K, NJ = 2 * K + 1;
+  __shared__ __attribute__((aligned(16))) int16_t sp[G_INST][K][256];
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
+  __shared__ uint32_t bad[G_INST];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+  if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
+
+  // r^ = NTT(CBD_eta1(PRF(r, j)))
+  for (int q = w.g; q < G_INST * K; q += 8) {
+    const int li = q / K, j = q % K;
+    const int gi = min(inst0 + li, n - 1);
+    int c[8];
+    cbd_contig<P::ETA1>(prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE, w.t, c);
+    KY_GSYNC();
+    lds_put_contig(wk[w.g], w.t, c);
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], w.t, c);
+    lds_put_contig(sp[li][j], w.t, c);
+  }
+  KY_GSYNC();
+  // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
+  for (int q = w.g; q < G_INST * (K + 1); q += 8) {
+    const int li = q / (K + 1), i = q % (K + 1);
+    const int gi = min(inst0 + li, n - 1);
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (i < K) {
+        ld_coef8(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
+      } else {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
+        frombytes12(s[0], s[1], s[2], a);
+      }
+      lds_get_contig(sp[li][j], w.t, b);
+      basemul_acc(acc, a, b, w.t);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
+    ntt_inv(wk[w.g], w.t, acc);
+    stride_to_contig(wk[w.g], w.t, acc);
+    cbd_contig<2>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE, w.t, b);  // nonce K+i (i==K: 2K)
+    if (i < K) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k] + b[k]);
+      compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, acc);
+    } else {
+      frommsg_contig(small[(size_t)gi * SMALL + w.t], a);
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k] + b[k] + a[k]);
+      compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, acc);
+    }
+  }
+  KY_GSYNC();
+  // the workgroup's ciphertexts are one contiguous run of global memory
+  const int nvalid = min(G_INST, n - inst0);
+  const uint4* src = reinterpret_cast<const uint4*>(&ctb[0][0]);
+  uint4* dst = reinterpret_cast<uint4*>(ct + (size_t)inst0 * P::CTB);
+  for (int o = threadIdx.x; o < nvalid * (P::CTB / 16); o += 256) {
+    if constexpr (CMP) {
+      uint4 x = src[o], y = dst[o];
+      if ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) atomicOr(&bad[o / (P::CTB / 16)], 1u);
+    } else {
+      dst[o] = src[o];
+    }
+  }
+  if constexpr (CMP) {
+    KY_GSYNC();
+    if (threadIdx.x < nvalid)
+      *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + threadIdx.x) * SMALL + 96) = bad[threadIdx.x];
+  }
+}
+
+// ------------------------------------------------------------------ decryption arithmetic
+// ref/indcpa.c:318-328: m' = tomsg(v - invntt(s^ . NTT(decompress(u))))
+template <class P>
+__global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
+                                                   uint8_t* __restrict__ small) {
+  constexpr int K = P::K;
+  __shared__ __attribute__((aligned(16))) int16_t uh[G_INST][K][256];
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+
+  for (int q = w.g; q < G_INST * K; q += 8) {
+    const int li = q / K, j = q % K;
+    const int gi = min(inst0 + li, n - 1);
+    int c[8];
+    decompress_contig<P::DU>(ct + (size_t)gi * P::CTB + P::UB * j, w.t, c);
+    KY_GSYNC();
+    lds_put_contig(wk[w.g], w.t, c);
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], w.t, c);
+    lds_put_contig(uh[li][j], w.t, c);
+  }
+  KY_GSYNC();
+  {
+    const int li = w.g;  // G_INST == number of groups: one result polynomial each
+    const int gi = min(inst0 + li, n - 1);
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const uint32_t* s = reinterpret_cast<const uint32_t*>(sk + (size_t)gi * P::SKB + 384 * j) + 3 * w.t;
+      frombytes12(s[0], s[1], s[2], a);
+      lds_get_contig(uh[li][j], w.t, b);
+      basemul_acc(acc, a, b, w.t);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
+    ntt_inv(wk[w.g], w.t, acc);
+    stride_to_contig(wk[w.g], w.t, acc);
+    decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, b);
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = barrett(b[k] - acc[k]);
+    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)tomsg_contig(acc);
+  }
+}
+
+// ------------------------------------------------------------------ standalone polynomial kernels
+// (BASELINE.json config 2: batched NTT / basemul / inverse NTT on dense
+// arrays of int16[256] polynomials; 8 polynomials per 256-thread workgroup)
+__global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int c[8];
+  ld_coef8(r + pi * 256, w.t, c);
+  lds_put_contig(wk[w.g], w.t, c);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, c);
+  if (live) lds_put_contig(r + pi * 256, w.t, c);
+}
+
+__global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __restrict__ r) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int c[8];
+  ld_coef8(r + pi * 256, w.t, c);
+  ntt_inv(wk[w.g], w.t, c);
+  stride_to_contig(wk[w.g], w.t, c);
+  if (live) lds_put_contig(r + pi * 256, w.t, c);
+}
+
+// r = a o b (Montgomery domain), no reduction beyond basemul's own.  ref/poly.c:273-280
+__global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
+                                                      const int16_t* __restrict__ b) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[8], y[8];
+  ld_coef8(a + pi * 256, w.t, x);
+  ld_coef8(b + pi * 256, w.t, y);
+  basemul_acc(acc, x, y, w.t);
+  lds_put_contig(r + pi * 256, w.t, acc);
+}
+
+// fused: r = invntt_tomont( poly_ntt(a) o poly_ntt(b) ) -- one HBM round trip
+// per operand, everything else in registers/LDS.
+__global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
+                                                        const int16_t* __restrict__ b) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int x[8], y[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ld_coef8(a + pi * 256, w.t, x);
+  lds_put_contig(wk[w.g], w.t, x);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, x);
+  ld_coef8(b + pi * 256, w.t, y);
+  KY_GSYNC();
+  lds_put_contig(wk[w.g], w.t, y);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, y);
+  basemul_acc(acc, x, y, w.t);
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
+  ntt_inv(wk[w.g], w.t, acc);
+  stride_to_contig(wk[w.g], w.t, acc);
+  if (live) lds_put_contig(r + pi * 256, w.t, acc);
+}
+
+}  // namespace ky

@@ -1,0 +1,405 @@
+// kyber_hip.hip -- C-ABI of libkyber_hip.so (include/kyber_batch.h,
+// include/kyber_api.h): workspace management and the kernel sequences for
+// batched keypair / encaps / decaps.  There is no CPU fallback anywhere in
+// this file: every result is produced by the gfx950 kernels in kem_kernels.h.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sys/random.h>
+#include <unistd.h>
+
+#include "../../include/kyber_batch.h"
+#include "../../include/kyber_api.h"
+#include "kem_kernels.h"
+
+using namespace ky;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return KYBER_HIP_EHIP;
+}
+#define HIP_TRY(call)                                    \
+  do {                                                   \
+    hipError_t e_ = (call);                              \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);    \
+  } while (0)
+
+// ---- per-device workspace --------------------------------------------------
+constexpr int MAX_DEV = 64;
+constexpr size_t DEFAULT_CHUNK = 1u << 17;
+struct Workspace {
+  void* base = nullptr;
+  size_t bytes = 0;
+};
+Workspace g_ws[MAX_DEV];
+size_t g_chunk = DEFAULT_CHUNK;
+std::mutex g_mu;
+
+int ws_reserve(size_t bytes, uint8_t** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
+  Workspace& w = g_ws[dev];
+  if (w.bytes < bytes) {
+    if (w.base) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(w.base));
+      w.base = nullptr;
+      w.bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&w.base, bytes));
+    w.bytes = bytes;
+  }
+  *out = static_cast<uint8_t*>(w.base);
+  return 0;
+}
+
+template <class P>
+struct Layout {
+  static constexpr size_t MAT = (size_t)P::NMAT * 512;
+  static constexpr size_t PRF = (size_t)(2 * P::K + 1) * P::PRF_STRIDE;
+  static constexpr size_t PER = MAT + PRF + SMALL;
+  int16_t* mat;
+  uint8_t* prf;
+  uint8_t* small;
+  int carve(size_t chunk) {
+    uint8_t* b;
+    int rc = ws_reserve(chunk * PER, &b);
+    if (rc) return rc;
+    mat = reinterpret_cast<int16_t*>(b);
+    prf = b + chunk * MAT;
+    small = prf + chunk * PRF;
+    return 0;
+  }
+};
+
+inline unsigned blocks(size_t items, unsigned per) { return (unsigned)((items + per - 1) / per); }
+
+#define LAUNCH_CHECK(name)                                      \
+  do {                                                          \
+    hipError_t e_ = hipGetLastError();                          \
+    if (e_ != hipSuccess) return hip_fail(e_, "launch " name);  \
+  } while (0)
+
+// ---- the three pipelines (device pointers) -----------------------------------
+template <class P>
+int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t chunk = n < g_chunk ? n : g_chunk;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* c = coins + o * 64;
+    uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
+    k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small);
+    LAUNCH_CHECK("k_kp_pre");
+    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat);
+    LAUNCH_CHECK("k_sample_matrix");
+    k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf);
+    LAUNCH_CHECK("k_prf");
+    k_kp_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, L.small, L.mat, L.prf, p, s);
+    LAUNCH_CHECK("k_kp_arith");
+    k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s);
+    LAUNCH_CHECK("k_kp_post");
+  }
+  return 0;
+}
+
+template <class P>
+int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t chunk = n < g_chunk ? n : g_chunk;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* p = pk + o * P::PKB;
+    uint8_t* c = ct + o * P::CTB;
+    k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small);
+    LAUNCH_CHECK("k_enc_pre");
+    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat);
+    LAUNCH_CHECK("k_sample_matrix");
+    k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf);
+    LAUNCH_CHECK("k_prf");
+    k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, P::PKB, L.small, L.mat, L.prf, c);
+    LAUNCH_CHECK("k_enc_arith");
+    k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32);
+    LAUNCH_CHECK("k_post");
+  }
+  return 0;
+}
+
+template <class P>
+int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t chunk = n < g_chunk ? n : g_chunk;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* c = ct + o * P::CTB;
+    const uint8_t* s = sk + o * P::SKB;
+    k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, L.small);
+    LAUNCH_CHECK("k_dec_arith");
+    k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small);
+    LAUNCH_CHECK("k_dec_mid");
+    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat);
+    LAUNCH_CHECK("k_sample_matrix");
+    k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf);
+    LAUNCH_CHECK("k_prf");
+    // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
+    k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, P::SKB, L.small, L.mat, L.prf,
+                                                             const_cast<uint8_t*>(c));
+    LAUNCH_CHECK("k_enc_arith(cmp)");
+    k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32);
+    LAUNCH_CHECK("k_post");
+  }
+  return 0;
+}
+
+template <class P>
+int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
+  if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
+  k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat);
+  LAUNCH_CHECK("k_sample_matrix");
+  return 0;
+}
+
+// ---- host-pointer wrappers ---------------------------------------------------
+struct DevBuf {
+  uint8_t* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), bytes ? bytes : 16));
+    return 0;
+  }
+};
+
+int fill_coins(uint8_t* dst_dev, const uint8_t* coins, size_t bytes) {
+  if (coins) {
+    HIP_TRY(hipMemcpy(dst_dev, coins, bytes, hipMemcpyHostToDevice));
+    return 0;
+  }
+  uint8_t* tmp = static_cast<uint8_t*>(malloc(bytes ? bytes : 1));
+  if (!tmp) return KYBER_HIP_EINVAL;
+  randombytes(tmp, bytes);
+  hipError_t e = hipMemcpy(dst_dev, tmp, bytes, hipMemcpyHostToDevice);
+  memset(tmp, 0, bytes);
+  free(tmp);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(coins)");
+  return 0;
+}
+
+template <class P>
+int keypair_host(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
+  DevBuf dpk, dsk, dc;
+  if (int rc = dpk.alloc(n * P::PKB)) return rc;
+  if (int rc = dsk.alloc(n * P::SKB)) return rc;
+  if (int rc = dc.alloc(n * 64)) return rc;
+  if (int rc = fill_coins(dc.p, coins, n * 64)) return rc;
+  if (int rc = keypair_dev<P>(n, dpk.p, dsk.p, dc.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(pk, dpk.p, n * P::PKB, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sk, dsk.p, n * P::SKB, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+template <class P>
+int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
+  DevBuf dpk, dct, dss, dc;
+  if (int rc = dpk.alloc(n * P::PKB)) return rc;
+  if (int rc = dct.alloc(n * P::CTB)) return rc;
+  if (int rc = dss.alloc(n * 32)) return rc;
+  if (int rc = dc.alloc(n * 32)) return rc;
+  HIP_TRY(hipMemcpy(dpk.p, pk, n * P::PKB, hipMemcpyHostToDevice));
+  if (int rc = fill_coins(dc.p, coins, n * 32)) return rc;
+  if (int rc = enc_dev<P>(n, dct.p, dss.p, dpk.p, dc.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(ct, dct.p, n * P::CTB, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+template <class P>
+int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
+  DevBuf dsk, dct, dss;
+  if (int rc = dsk.alloc(n * P::SKB)) return rc;
+  if (int rc = dct.alloc(n * P::CTB)) return rc;
+  if (int rc = dss.alloc(n * 32)) return rc;
+  HIP_TRY(hipMemcpy(dsk.p, sk, n * P::SKB, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dct.p, ct, n * P::CTB, hipMemcpyHostToDevice));
+  if (int rc = dec_dev<P>(n, dss.p, dct.p, dsk.p, nullptr)) return rc;
+  HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// dispatch on the run-time parameter set
+#define DISPATCH(K, NINETIES, EXPR512, EXPR768, EXPR1024) \
+  do {                                                     \
+    if ((NINETIES)) return KYBER_HIP_ENOSYS;               \
+    switch (K) {                                           \
+      case 2: return EXPR512;                              \
+      case 3: return EXPR768;                              \
+      case 4: return EXPR1024;                             \
+      default: return KYBER_HIP_EINVAL;                    \
+    }                                                      \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+size_t kyber_hip_pk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)384 * k + 32; }
+size_t kyber_hip_sk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)768 * k + 96; }
+size_t kyber_hip_ct_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)32 * ((k == 4 ? 11 : 10) * k + (k == 4 ? 5 : 4)); }
+
+int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, void* stream) {
+  if (!pk || !sk || !coins) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, keypair_dev<Par<2>>(n, pk, sk, coins, st), keypair_dev<Par<3>>(n, pk, sk, coins, st),
+           keypair_dev<Par<4>>(n, pk, sk, coins, st));
+}
+int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
+                        void* stream) {
+  if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, enc_dev<Par<2>>(n, ct, ss, pk, coins, st), enc_dev<Par<3>>(n, ct, ss, pk, coins, st),
+           enc_dev<Par<4>>(n, ct, ss, pk, coins, st));
+}
+int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
+  if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, dec_dev<Par<2>>(n, ss, ct, sk, st), dec_dev<Par<3>>(n, ss, ct, sk, st),
+           dec_dev<Par<4>>(n, ss, ct, sk, st));
+}
+
+int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
+  if (!pk || !sk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  DISPATCH(k, nineties, keypair_host<Par<2>>(n, pk, sk, coins), keypair_host<Par<3>>(n, pk, sk, coins),
+           keypair_host<Par<4>>(n, pk, sk, coins));
+}
+int kyber_batch_enc(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
+  if (!ct || !ss || !pk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  DISPATCH(k, nineties, enc_host<Par<2>>(n, ct, ss, pk, coins), enc_host<Par<3>>(n, ct, ss, pk, coins),
+           enc_host<Par<4>>(n, ct, ss, pk, coins));
+}
+int kyber_batch_dec(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
+  if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  DISPATCH(k, nineties, dec_host<Par<2>>(n, ss, ct, sk), dec_host<Par<3>>(n, ss, ct, sk), dec_host<Par<4>>(n, ss, ct, sk));
+}
+
+int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, const uint8_t* seeds, int transposed, void* stream) {
+  if (!mat || !seeds) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, gen_matrix_dev<Par<2>>(n, mat, seeds, transposed, st),
+           gen_matrix_dev<Par<3>>(n, mat, seeds, transposed, st), gen_matrix_dev<Par<4>>(n, mat, seeds, transposed, st));
+}
+
+int kyber_batch_poly_ntt_dev(size_t npoly, int16_t* r, void* stream) {
+  if (!r) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  k_poly_ntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r);
+  LAUNCH_CHECK("k_poly_ntt");
+  return 0;
+}
+int kyber_batch_poly_invntt_dev(size_t npoly, int16_t* r, void* stream) {
+  if (!r) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  k_poly_invntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r);
+  LAUNCH_CHECK("k_poly_invntt");
+  return 0;
+}
+int kyber_batch_poly_basemul_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
+  if (!r || !a || !b) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  k_poly_basemul<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b);
+  LAUNCH_CHECK("k_poly_basemul");
+  return 0;
+}
+int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
+  if (!r || !a || !b) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  k_poly_mul_fused<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b);
+  LAUNCH_CHECK("k_poly_mul_fused");
+  return 0;
+}
+
+int kyber_hip_set_chunk(size_t instances) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_chunk = instances ? instances : DEFAULT_CHUNK;
+  return 0;
+}
+
+int kyber_hip_release(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
+  if (g_ws[dev].base) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(g_ws[dev].base));
+    g_ws[dev] = Workspace{};
+  }
+  return 0;
+}
+
+const char* kyber_hip_last_error(void) { return g_err; }
+
+// weak default entropy source; aborts like the reference's on OS failure (ref/randombytes.c:49-50)
+__attribute__((weak)) void randombytes(uint8_t* out, size_t outlen) {
+  while (outlen) {
+    ssize_t r = getrandom(out, outlen > 256 ? 256 : outlen, 0);
+    if (r < 0) abort();
+    out += r;
+    outlen -= (size_t)r;
+  }
+}
+
+// ---- per-set batch spellings + the namespaced single-call API ---------------------
+#define DEFINE_SET(NAME, KK, N90)                                                                              \
+  int NAME##_batch_keypair(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {                         \
+    return kyber_batch_keypair(KK, N90, n, pk, sk, coins);                                                     \
+  }                                                                                                            \
+  int NAME##_batch_enc(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {          \
+    return kyber_batch_enc(KK, N90, n, ct, ss, pk, coins);                                                     \
+  }                                                                                                            \
+  int NAME##_batch_dec(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {                          \
+    return kyber_batch_dec(KK, N90, n, ss, ct, sk);                                                            \
+  }                                                                                                            \
+  int pqcrystals_##NAME##_hip_keypair(uint8_t* pk, uint8_t* sk) {                                              \
+    uint8_t coins[64];                                                                                         \
+    randombytes(coins, 32);      /* d,  ref/indcpa.c:215 */                                                    \
+    randombytes(coins + 32, 32); /* z,  ref/kem.c:32     */                                                    \
+    return kyber_batch_keypair(KK, N90, 1, pk, sk, coins);                                                     \
+  }                                                                                                            \
+  int pqcrystals_##NAME##_hip_enc(uint8_t* ct, uint8_t* ss, const uint8_t* pk) {                               \
+    uint8_t coins[32];                                                                                         \
+    randombytes(coins, 32); /* m0, ref/kem.c:59 */                                                             \
+    return kyber_batch_enc(KK, N90, 1, ct, ss, pk, coins);                                                     \
+  }                                                                                                            \
+  int pqcrystals_##NAME##_hip_dec(uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {                         \
+    return kyber_batch_dec(KK, N90, 1, ss, ct, sk);                                                            \
+  }
+
+DEFINE_SET(kyber512, 2, 0)
+DEFINE_SET(kyber768, 3, 0)
+DEFINE_SET(kyber1024, 4, 0)
+DEFINE_SET(kyber512_90s, 2, 1)
+DEFINE_SET(kyber768_90s, 3, 1)
+DEFINE_SET(kyber1024_90s, 4, 1)
+
+}  // extern "C"

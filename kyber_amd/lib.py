@@ -1,0 +1,230 @@
+"""ctypes binding of libkyber_hip.so (see include/kyber_batch.h).
+
+Mirrors the reference's three-function KEM interface (ref/api.h:16-18,39-41,
+62-64; ref/kem.c:23-127) in batched form:
+
+    kem = KyberHip(3)                    # Kyber768
+    pk, sk = kem.keypair(coins)          # coins: uint8[n,64] = d||z per instance
+    ct, ss = kem.enc(pk, coins)          # coins: uint8[n,32] = m0 per instance
+    ss2    = kem.dec(ct, sk)
+
+Host calls take/return numpy uint8 arrays; the *_dev calls take torch CUDA
+uint8 tensors (device-resident, no PCIe traffic) and enqueue on torch's
+current stream.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PARAMETER_SETS = {
+    # name: (k, nineties)                                   ref/params.h:11-31
+    "kyber512": (2, 0), "kyber768": (3, 0), "kyber1024": (4, 0),
+    "kyber512-90s": (2, 1), "kyber768-90s": (3, 1), "kyber1024-90s": (4, 1),
+}
+
+
+class KyberHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libkyber_hip.so")
+
+
+def sizes(k):
+    """(pk, sk, ct) bytes of parameter set k -- ref/params.h:63-66."""
+    du, dv = (11, 5) if k == 4 else (10, 4)
+    return 384 * k + 32, 768 * k + 96, 32 * (du * k + dv)
+
+
+def library():
+    """Load libkyber_hip.so once; no fallback if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise KyberHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    u8p, i16p, sz, vp, ci = (ctypes.c_void_p,) * 2 + (ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int)
+    sig = {
+        "kyber_batch_keypair": [ci, ci, sz, u8p, u8p, u8p],
+        "kyber_batch_enc": [ci, ci, sz, u8p, u8p, u8p, u8p],
+        "kyber_batch_dec": [ci, ci, sz, u8p, u8p, u8p],
+        "kyber_batch_keypair_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
+        "kyber_batch_enc_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
+        "kyber_batch_dec_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
+        "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
+        "kyber_batch_poly_ntt_dev": [sz, i16p, vp],
+        "kyber_batch_poly_invntt_dev": [sz, i16p, vp],
+        "kyber_batch_poly_basemul_dev": [sz, i16p, i16p, i16p, vp],
+        "kyber_batch_poly_mul_fused_dev": [sz, i16p, i16p, i16p, vp],
+        "kyber_hip_set_chunk": [sz],
+        "kyber_hip_release": [],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    for name in ("kyber_hip_pk_bytes", "kyber_hip_sk_bytes", "kyber_hip_ct_bytes"):
+        fn = getattr(lib, name)
+        fn.argtypes = [ctypes.c_int]
+        fn.restype = ctypes.c_size_t
+    lib.kyber_hip_last_error.restype = ctypes.c_char_p
+    _LIB = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = library().kyber_hip_last_error().decode()
+        names = {-1: "EINVAL", -2: "ENOSYS (parameter set not built)", -3: "EHIP"}
+        raise KyberHipError("%s failed: %s %s" % (what, names.get(rc, rc), msg))
+
+
+def _np_u8(a, shape, name):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.shape != shape:
+        raise ValueError("%s: expected shape %s, got %s" % (name, shape, a.shape))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _torch_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _tptr(t, nbytes, name):
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous CUDA tensor" % name)
+    if t.numel() * t.element_size() != nbytes:
+        raise ValueError("%s: expected %d bytes, got %d" % (name, nbytes, t.numel() * t.element_size()))
+    if t.data_ptr() % 16:
+        raise ValueError("%s must be 16-byte aligned" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class KyberHip:
+    """One parameter set of the KEM (k = 2, 3, 4; nineties selects the -90s variant)."""
+
+    def __init__(self, k=3, nineties=False):
+        if k not in (2, 3, 4):
+            raise ValueError("k must be 2, 3 or 4")
+        self.k, self.nineties = k, int(bool(nineties))
+        self.pk_bytes, self.sk_bytes, self.ct_bytes = sizes(k)
+        self.lib = library()
+
+    @classmethod
+    def from_name(cls, name):
+        k, n90 = PARAMETER_SETS[name.lower()]
+        return cls(k, n90)
+
+    # ---- host arrays ----
+    def keypair(self, coins=None, n=None):
+        if coins is not None:
+            coins = np.ascontiguousarray(coins, dtype=np.uint8).reshape(-1, 64)
+            n = coins.shape[0]
+        elif n is None:
+            raise ValueError("give coins or n")
+        pk = np.empty((n, self.pk_bytes), np.uint8)
+        sk = np.empty((n, self.sk_bytes), np.uint8)
+        _check(self.lib.kyber_batch_keypair(self.k, self.nineties, n, _ptr(pk), _ptr(sk),
+                                            _ptr(coins) if coins is not None else None), "kyber_batch_keypair")
+        return pk, sk
+
+    def enc(self, pk, coins=None):
+        pk = np.ascontiguousarray(pk, dtype=np.uint8).reshape(-1, self.pk_bytes)
+        n = pk.shape[0]
+        if coins is not None:
+            coins = _np_u8(np.asarray(coins).reshape(-1, 32), (n, 32), "coins")
+        ct = np.empty((n, self.ct_bytes), np.uint8)
+        ss = np.empty((n, 32), np.uint8)
+        _check(self.lib.kyber_batch_enc(self.k, self.nineties, n, _ptr(ct), _ptr(ss), _ptr(pk),
+                                        _ptr(coins) if coins is not None else None), "kyber_batch_enc")
+        return ct, ss
+
+    def dec(self, ct, sk):
+        ct = np.ascontiguousarray(ct, dtype=np.uint8).reshape(-1, self.ct_bytes)
+        n = ct.shape[0]
+        sk = _np_u8(np.asarray(sk).reshape(-1, self.sk_bytes), (n, self.sk_bytes), "sk")
+        ss = np.empty((n, 32), np.uint8)
+        _check(self.lib.kyber_batch_dec(self.k, self.nineties, n, _ptr(ss), _ptr(ct), _ptr(sk)), "kyber_batch_dec")
+        return ss
+
+    # ---- device tensors (torch, uint8, CUDA) ----
+    def keypair_dev(self, coins, pk=None, sk=None):
+        import torch
+        n = coins.numel() // 64
+        pk = torch.empty((n, self.pk_bytes), dtype=torch.uint8, device=coins.device) if pk is None else pk
+        sk = torch.empty((n, self.sk_bytes), dtype=torch.uint8, device=coins.device) if sk is None else sk
+        _check(self.lib.kyber_batch_keypair_dev(self.k, self.nineties, n, _tptr(pk, n * self.pk_bytes, "pk"),
+                                                _tptr(sk, n * self.sk_bytes, "sk"), _tptr(coins, n * 64, "coins"),
+                                                _torch_stream()), "kyber_batch_keypair_dev")
+        return pk, sk
+
+    def enc_dev(self, pk, coins, ct=None, ss=None):
+        import torch
+        n = coins.numel() // 32
+        ct = torch.empty((n, self.ct_bytes), dtype=torch.uint8, device=pk.device) if ct is None else ct
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=pk.device) if ss is None else ss
+        _check(self.lib.kyber_batch_enc_dev(self.k, self.nineties, n, _tptr(ct, n * self.ct_bytes, "ct"),
+                                            _tptr(ss, n * 32, "ss"), _tptr(pk, n * self.pk_bytes, "pk"),
+                                            _tptr(coins, n * 32, "coins"), _torch_stream()), "kyber_batch_enc_dev")
+        return ct, ss
+
+    def dec_dev(self, ct, sk, ss=None):
+        import torch
+        n = ct.numel() // self.ct_bytes
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device) if ss is None else ss
+        _check(self.lib.kyber_batch_dec_dev(self.k, self.nineties, n, _tptr(ss, n * 32, "ss"),
+                                            _tptr(ct, n * self.ct_bytes, "ct"), _tptr(sk, n * self.sk_bytes, "sk"),
+                                            _torch_stream()), "kyber_batch_dec_dev")
+        return ss
+
+    def gen_matrix_dev(self, seeds, transposed):
+        """seeds: uint8[n,32] CUDA tensor -> int16[n, k*k, 256] (ref/indcpa.c:164-192)."""
+        import torch
+        n = seeds.numel() // 32
+        mat = torch.empty((n, self.k * self.k, 256), dtype=torch.int16, device=seeds.device)
+        _check(self.lib.kyber_batch_gen_matrix_dev(self.k, self.nineties, n, _tptr(mat, mat.numel() * 2, "mat"),
+                                                   _tptr(seeds, n * 32, "seeds"), int(bool(transposed)),
+                                                   _torch_stream()), "kyber_batch_gen_matrix_dev")
+        return mat
+
+
+# ---- batched polynomial kernels on torch int16 tensors [npoly, 256] ----
+def _poly_call(name, *tensors):
+    lib = library()
+    npoly = tensors[0].numel() // 256
+    args = [_tptr(t, npoly * 512, "poly") for t in tensors]
+    _check(getattr(lib, name)(npoly, *args, _torch_stream()), name)
+
+
+def poly_ntt_(r):
+    _poly_call("kyber_batch_poly_ntt_dev", r)
+    return r
+
+
+def poly_invntt_(r):
+    _poly_call("kyber_batch_poly_invntt_dev", r)
+    return r
+
+
+def poly_basemul(r, a, b):
+    _poly_call("kyber_batch_poly_basemul_dev", r, a, b)
+    return r
+
+
+def poly_mul_fused(r, a, b):
+    _poly_call("kyber_batch_poly_mul_fused_dev", r, a, b)
+    return r
