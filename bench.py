@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- Kyber768 batched encaps+decaps throughput on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One "step" = one pass of the hot path over one batch: B encapsulations
+followed by B decapsulations (device-resident pk/sk/ct/ss, keys generated once
+by the batched keypair before the timed region).  B defaults to 2^20 per GPU
+(BASELINE.json configs[2]).  Instances are independent, so N GPUs run N
+disjoint batches with no data-path collective ("weak" scaling); the only
+torch.distributed traffic is the barrier and the max-over-ranks of the time.
+
+Prints ONE JSON line (rank 0) with the whole-job rate, a `roofline` object for
+the dominant kernel (k_sample_matrix: SHAKE128 matrix expansion + rejection
+sampling) measured live with HIP events, and a `cpu_baseline` object: the
+reference's own avx2/ (or ref/) code from oracle/_ref timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+K = 3  # Kyber768
+SEED0 = 0x4B59424552  # "KYBER", SURVEY.md §8(d)
+
+# algorithmic constants (restated in DESIGN.md)
+KECCAK_LANE_OPS = 6240           # 32-bit lane-ops per Keccak-f[1600] as written in the reference
+VALU_PEAK_TLOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, full-rate 32-bit int ops
+HBM_PEAK_GBS = 8000.0
+ENCDEC_BYTES = 5856              # compulsory HBM bytes per Kyber768 enc+dec
+ENCDEC_PERMS = 100               # Keccak-f per Kyber768 enc+dec
+MATRIX_ENTRY_PERMS = 3           # SHAKE128 blocks per matrix entry (4th block: 0.8 % of entries)
+MATRIX_ENTRY_BYTES = 512 + 32 / 9.0
+
+
+def cpu_baseline(budget_s=20.0):
+    """Time the reference's own code (oracle/_ref, built from /root/reference's
+    ref/ and avx2/ sources) on the host cores; falls back to the oracle port."""
+    import numpy as np
+    import oracle_lib
+
+    threads = min(16, os.cpu_count() or 1)
+    rng = np.random.default_rng(7)
+    kind, impl, lib = "port", "oracle", None
+    for cand in (("avx2",) if oracle_lib.has_avx2() else ()) + ("ref",):
+        try:
+            lib = oracle_lib.RefLib(cand, K)
+            kind, impl = "reference", cand
+            break
+        except (OSError, FileNotFoundError):
+            continue
+    if lib is None:
+        o = oracle_lib.load_oracle()
+
+        class _Port:
+            def keypair(self, c): return o.keypair(K, c)
+            def enc(self, pk, c): return o.enc(K, pk, c)
+            def dec(self, ct, sk): return o.dec(K, ct, sk)
+        lib = _Port()
+
+    # calibrate on one core
+    n0 = 512
+    kc, ec = rng.integers(0, 256, (n0, 64), dtype=np.uint8), rng.integers(0, 256, (n0, 32), dtype=np.uint8)
+    pk, sk = lib.keypair(kc)
+    t0 = time.perf_counter()
+    ct, ss = lib.enc(pk, ec)
+    ss2 = lib.dec(ct, sk)
+    t1 = time.perf_counter() - t0
+    assert (ss == ss2).all()
+    one_core = n0 / t1
+    per_thread = max(n0, int(one_core * budget_s * 0.5))
+    kc = rng.integers(0, 256, (per_thread, 64), dtype=np.uint8)
+    ec = rng.integers(0, 256, (per_thread, 32), dtype=np.uint8)
+    pk, sk = lib.keypair(kc)
+
+    def work():
+        c, s = lib.enc(pk, ec)
+        lib.dec(c, sk)
+
+    ths = [threading.Thread(target=work) for _ in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {
+        "value": threads * per_thread / dt, "unit": "encaps+decaps/s", "cores": threads, "kind": kind,
+        "impl": impl, "one_core": one_core,
+        "sample": "Kyber768 enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="KEM instances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import kyber_amd
+    from kyber_amd import lib as kl
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dev = torch.device("cuda", local)
+    kem = kyber_amd.KyberHip(K)
+    n = args.batch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED0 + rank)
+    kcoins = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device=dev, generator=gen)
+    ecoins = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=gen)
+    pk, sk = kem.keypair_dev(kcoins)
+    ct = torch.empty((n, kem.ct_bytes), dtype=torch.uint8, device=dev)
+    ssb = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    ssa = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+
+    def step():
+        kem.enc_dev(pk, ecoins, ct, ssb)
+        kem.dec_dev(ct, sk, ssa)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness of what was just timed: every decapsulated secret equals the
+    # encapsulated one, and a strided sample is bit-exact against the oracle
+    assert torch.equal(ssa, ssb), "decaps != encaps shared secret"
+    parity = None
+    try:
+        import oracle_lib
+        o = oracle_lib.load_oracle()
+        idx = torch.arange(0, n, 4096, device=dev)
+        opk, osk = o.keypair(K, kcoins[idx].cpu().numpy())
+        oct_, oss = o.enc(K, opk, ecoins[idx].cpu().numpy())
+        parity = bool(np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk)
+                      and np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssa[idx].cpu().numpy(), oss))
+        assert parity, "strided sample differs from the oracle"
+    except (OSError, ImportError):
+        parity = None
+
+    # per-kernel durations: a separate, untimed pass with HIP events on the launch stream
+    roof = None
+    kernels = {}
+    if rank == 0:
+        kl.profile_enable(True)
+        reps = 3
+        for _ in range(reps):
+            step()
+        prof = kl.profile_read()
+        kl.profile_enable(False)
+        tot = sum(ms for _, ms in prof.values())
+        for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            kernels[name] = {"launches": cnt, "avg_ms": ms / cnt, "share": ms / tot}
+        dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
+        cnt, ms = prof[dom]
+        avg_s = ms / cnt * 1e-3
+        chunk = min(n, 1 << 17)
+        if dom == "k_sample_matrix":
+            entries = chunk * K * K
+            ops = entries * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS
+            bytes_ = entries * MATRIX_ENTRY_BYTES
+        else:  # fall back to whole-pipeline accounting for an unexpected dominant kernel
+            ops = chunk * ENCDEC_PERMS * KECCAK_LANE_OPS
+            bytes_ = chunk * ENCDEC_BYTES
+        ach = ops / avg_s * 1e-12
+        roof = {
+            "kernel": dom, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
+            "frac": ach / VALU_PEAK_TLOPS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
+            "units_per_launch": chunk * K * K if dom == "k_sample_matrix" else chunk,
+            "hbm": {"achieved": bytes_ / avg_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_ / avg_s * 1e-9 / HBM_PEAK_GBS},
+        }
+
+    if rank == 0:
+        total = n * world * args.steps
+        value = total / dt
+        out = {
+            "metric": "Kyber768 encaps+decaps/sec", "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16/u64",
+            "data": "synthetic (device-generated coins, seed 0x4B59424552)",
+            "config": {"workload": "Kyber768 batched encaps+decaps, %d instances per GPU per step, device-resident" % n,
+                       "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective"},
+            "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_oracle": parity},
+            "pipeline": {"valu_frac": value / world * ENCDEC_PERMS * KECCAK_LANE_OPS * 1e-12 / VALU_PEAK_TLOPS,
+                         "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never sink the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

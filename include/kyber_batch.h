@@ -105,6 +105,12 @@ int kyber_hip_set_chunk(size_t instances);
 int kyber_hip_release(void);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char *kyber_hip_last_error(void);
+/* Measurement aid (no counterpart in the reference): with profiling on, every
+ * kernel launch of the *_dev calls is bracketed by HIP events on its stream.
+ * kyber_hip_profile_read synchronises the device and writes one text line per
+ * kernel name, "<name> <launches> <total_ms>\n", into buf. */
+int kyber_hip_profile_enable(int on);
+int kyber_hip_profile_read(char *buf, size_t len);
 
 /* Entropy hook, same contract as the reference's (ref/randombytes.h:7).  The
  * library ships a weak default backed by getrandom(2); a program that defines

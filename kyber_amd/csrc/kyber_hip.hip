@@ -4,6 +4,9 @@
 // this file: every result is produced by the gfx950 kernels in kem_kernels.h.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <vector>
+#include <map>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,6 +90,37 @@ inline unsigned blocks(size_t items, unsigned per) { return (unsigned)((items + 
     if (e_ != hipSuccess) return hip_fail(e_, "launch " name);  \
   } while (0)
 
+// ---- optional per-kernel timing (HIP events on the launch stream) -----------------
+// Off by default; bench.py switches it on for a separate, untimed pass to get
+// each kernel's average launch duration for the roofline line.
+struct ProfRec {
+  const char* name;
+  hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+inline void prof_begin(hipStream_t st, hipEvent_t* a) {
+  if (!g_prof_on) return;
+  (void)hipEventCreate(a);
+  (void)hipEventRecord(*a, st);
+}
+inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
+  if (!g_prof_on) return;
+  hipEvent_t b;
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(b, st);
+  g_prof.push_back(ProfRec{name, a, b});
+}
+#define RUN(name, st, ...)        \
+  do {                            \
+    hipEvent_t ev_a_{};           \
+    prof_begin(st, &ev_a_);       \
+    __VA_ARGS__;                  \
+    LAUNCH_CHECK(name);           \
+    prof_end(name, st, ev_a_);    \
+  } while (0)
+
 // ---- the three pipelines (device pointers) -----------------------------------
 template <class P>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
@@ -98,16 +132,11 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
-    k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small);
-    LAUNCH_CHECK("k_kp_pre");
-    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat);
-    LAUNCH_CHECK("k_sample_matrix");
-    k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf);
-    LAUNCH_CHECK("k_prf");
-    k_kp_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, L.small, L.mat, L.prf, p, s);
-    LAUNCH_CHECK("k_kp_arith");
-    k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s);
-    LAUNCH_CHECK("k_kp_post");
+    RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
+    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    RUN("k_kp_arith", st, k_kp_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, L.small, L.mat, L.prf, p, s));
+    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
   }
   return 0;
 }
@@ -122,16 +151,11 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = pk + o * P::PKB;
     uint8_t* c = ct + o * P::CTB;
-    k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small);
-    LAUNCH_CHECK("k_enc_pre");
-    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat);
-    LAUNCH_CHECK("k_sample_matrix");
-    k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf);
-    LAUNCH_CHECK("k_prf");
-    k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, P::PKB, L.small, L.mat, L.prf, c);
-    LAUNCH_CHECK("k_enc_arith");
-    k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32);
-    LAUNCH_CHECK("k_post");
+    RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
+    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    RUN("k_enc_arith", st, k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, P::PKB, L.small, L.mat, L.prf, c));
+    RUN("k_post", st, k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
   }
   return 0;
 }
@@ -146,20 +170,14 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStre
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * P::SKB;
-    k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, L.small);
-    LAUNCH_CHECK("k_dec_arith");
-    k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small);
-    LAUNCH_CHECK("k_dec_mid");
-    k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat);
-    LAUNCH_CHECK("k_sample_matrix");
-    k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf);
-    LAUNCH_CHECK("k_prf");
+    RUN("k_dec_arith", st, k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, L.small));
+    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
+    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
-    k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, P::SKB, L.small, L.mat, L.prf,
-                                                             const_cast<uint8_t*>(c));
-    LAUNCH_CHECK("k_enc_arith(cmp)");
-    k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32);
-    LAUNCH_CHECK("k_post");
+    RUN("k_enc_arith_cmp", st, k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, P::SKB, L.small, L.mat, L.prf,
+                                                             const_cast<uint8_t*>(c)));
+    RUN("k_post", st, k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
   }
   return 0;
 }
@@ -167,8 +185,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStre
 template <class P>
 int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
   if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
-  k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat);
-  LAUNCH_CHECK("k_sample_matrix");
+  RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
   return 0;
 }
 
@@ -312,29 +329,25 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, cons
 int kyber_batch_poly_ntt_dev(size_t npoly, int16_t* r, void* stream) {
   if (!r) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  k_poly_ntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r);
-  LAUNCH_CHECK("k_poly_ntt");
+  RUN("k_poly_ntt", static_cast<hipStream_t>(stream), k_poly_ntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r));
   return 0;
 }
 int kyber_batch_poly_invntt_dev(size_t npoly, int16_t* r, void* stream) {
   if (!r) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  k_poly_invntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r);
-  LAUNCH_CHECK("k_poly_invntt");
+  RUN("k_poly_invntt", static_cast<hipStream_t>(stream), k_poly_invntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r));
   return 0;
 }
 int kyber_batch_poly_basemul_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
   if (!r || !a || !b) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  k_poly_basemul<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b);
-  LAUNCH_CHECK("k_poly_basemul");
+  RUN("k_poly_basemul", static_cast<hipStream_t>(stream), k_poly_basemul<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b));
   return 0;
 }
 int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
   if (!r || !a || !b) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  k_poly_mul_fused<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b);
-  LAUNCH_CHECK("k_poly_mul_fused");
+  RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), k_poly_mul_fused<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b));
   return 0;
 }
 
@@ -358,6 +371,38 @@ int kyber_hip_release(void) {
 }
 
 const char* kyber_hip_last_error(void) { return g_err; }
+
+int kyber_hip_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int kyber_hip_profile_read(char* buf, size_t len) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIP_TRY(hipDeviceSynchronize());
+  std::map<std::string, std::pair<double, long>> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    auto& e = agg[r.name];
+    e.first += ms;
+    e.second += 1;
+  }
+  size_t o = 0;
+  if (len) buf[0] = 0;
+  for (auto& kv : agg) {
+    int w = snprintf(buf + o, o < len ? len - o : 0, "%s %ld %.6f\n", kv.first.c_str(), kv.second.second, kv.second.first);
+    if (w < 0 || o + (size_t)w >= len) break;
+    o += (size_t)w;
+  }
+  return 0;
+}
 
 // weak default entropy source; aborts like the reference's on OS failure (ref/randombytes.c:49-50)
 __attribute__((weak)) void randombytes(uint8_t* out, size_t outlen) {

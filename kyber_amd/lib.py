@@ -66,6 +66,8 @@ def library():
         "kyber_batch_poly_basemul_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_batch_poly_mul_fused_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_hip_set_chunk": [sz],
+        "kyber_hip_profile_enable": [ci],
+        "kyber_hip_profile_read": [ctypes.c_char_p, sz],
         "kyber_hip_release": [],
     }
     for name, args in sig.items():
@@ -200,6 +202,26 @@ class KyberHip:
                                                    _tptr(seeds, n * 32, "seeds"), int(bool(transposed)),
                                                    _torch_stream()), "kyber_batch_gen_matrix_dev")
         return mat
+
+
+def profile_enable(on):
+    """Bracket every kernel launch with HIP events (measurement aid)."""
+    _check(library().kyber_hip_profile_enable(int(bool(on))), "kyber_hip_profile_enable")
+
+
+def profile_read():
+    """-> {kernel name: (launches, total_ms)} since profile_enable(True)."""
+    buf = ctypes.create_string_buffer(8192)
+    _check(library().kyber_hip_profile_read(buf, len(buf)), "kyber_hip_profile_read")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def set_chunk(instances):
+    _check(library().kyber_hip_set_chunk(int(instances)), "kyber_hip_set_chunk")
 
 
 # ---- batched polynomial kernels on torch int16 tensors [npoly, 256] ----
