@@ -231,23 +231,35 @@ __device__ __forceinline__ uint32_t field12(const uint32_t (&H)[42]) {
   else return __builtin_amdgcn_alignbit(H[k + 1], H[k], s) & 0xFFFu;
 }
 
+// Candidate d is kept iff d < q.  (d - q) is negative exactly then, so bit 1 of
+// (d - q) >> 30 is the byte step of the 16-bit write cursor: four full-rate
+// VALU ops per candidate, no compare/select, no SGPR traffic.
+__device__ __forceinline__ uint32_t accept_step(uint32_t d) { return ((d - (uint32_t)Q) >> 30) & 2u; }
+
+// LDS addressed by its 32-bit byte offset, so the write cursor IS the ds_write address.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void lds_st16(uint32_t addr, uint32_t v) { *(lds_u16*)(uintptr_t)addr = (uint16_t)v; }
+
 template <int G>
-__device__ __forceinline__ void parse_group(const uint32_t (&H)[42], uint16_t*& wp) {
+__device__ __forceinline__ void parse_group(const uint32_t (&H)[42], uint32_t& waddr) {
   uint32_t d1 = field12<24 * G>(H), d2 = field12<24 * G + 12>(H);
-  *wp = (uint16_t)d1;
-  wp += (d1 < (uint32_t)Q) ? 1 : 0;
-  *wp = (uint16_t)d2;
-  wp += (d2 < (uint32_t)Q) ? 1 : 0;
+  lds_st16(waddr, d1);
+  waddr += accept_step(d1);
+  lds_st16(waddr, d2);
+  waddr += accept_step(d2);
 }
 template <int G0, int G1>
-__device__ __forceinline__ void parse_range(const uint32_t (&H)[42], uint16_t*& wp) {
+__device__ __forceinline__ void parse_range(const uint32_t (&H)[42], uint32_t& waddr) {
   if constexpr (G0 < G1) {
-    parse_group<G0>(H, wp);
-    parse_range<G0 + 1, G1>(H, wp);
+    parse_group<G0>(H, waddr);
+    parse_range<G0 + 1, G1>(H, waddr);
   }
 }
 
-template <class P>
+template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either)
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                        int transposed, int16_t* __restrict__ mat) {
   __shared__ uint32_t stage[4][64 * STAGE_DW];
@@ -269,6 +281,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   A[20].hi = 0x80000000u;
 
   uint32_t* row = stage[wave] + lane * STAGE_DW;
+  const uint32_t row_addr = lds_addr(row);
   uint32_t* tile = stage[wave];
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
   int ctr = valid ? 0 : 256;
@@ -279,20 +292,34 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
 #pragma unroll
     for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
     // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
-    uint16_t* wp0 = reinterpret_cast<uint16_t*>(row) + (ctr & 1);
-    uint16_t* wp = wp0;
-    parse_range<0, 56>(H, wp);
+    const uint32_t w0 = row_addr + 2u * (ctr & 1);
+    uint32_t waddr = w0;
+    if constexpr (ABLATE < 2) {
+      parse_range<0, 56>(H, waddr);
+    } else {
+#pragma unroll
+      for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
+      waddr += 2 * 91;
+    }
     const int c0 = ctr;
-    const int c1 = c0 + (int)(wp - wp0);
-    // drain: polynomial of lane p gets dwords [c0>>1, (min(c1,256)+1)>>1)
+    const int c1 = c0 + (int)((waddr - w0) >> 1);
+    // drain: the polynomial of lane p gets dwords [c0>>1, (min(c1,256)+1)>>1) of
+    // its row.  Eight rows per step, all LDS reads issued before the first
+    // store, so the LDS latency is paid once per step instead of once per row.
+    const int d0v = c0 >> 1;
+    const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
 #pragma unroll 1
-    for (int p = 0; p < 64; p++) {
-      const int pc0 = __builtin_amdgcn_readlane(c0, p);
-      if (pc0 >= 256) continue;
-      int pc1 = __builtin_amdgcn_readlane(c1, p);
-      pc1 = pc1 < 256 ? pc1 : 256;
-      const int d0 = pc0 >> 1, nd = ((pc1 + 1) >> 1) - d0;
-      if (lane < nd) out32[(job0 + p) * 128 + d0 + lane] = tile[p * STAGE_DW + lane];
+    for (int p0 = 0; p0 < (ABLATE ? 0 : 64); p0 += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = tile[(p0 + u) * STAGE_DW + lane];
+#pragma unroll
+      for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int d0 = __builtin_amdgcn_readlane(d0v, p0 + u), nd = __builtin_amdgcn_readlane(ndv, p0 + u);
+        if (lane < nd) out32[(job0 + p0 + u) * 128 + d0 + lane] = v[u];
+      }
     }
     // carry an unpaired last coefficient to slot 0 for the next block
     if (c0 < 256 && (c1 & 1)) {

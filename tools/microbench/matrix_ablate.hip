@@ -1,0 +1,30 @@
+// matrix_ablate.hip -- where does k_sample_matrix spend its time?  Runs the
+// product kernel (ABLATE=0) and two ablations (1: no drain, 2: no parse, no
+// drain) interleaved in one process on the same seeds.
+#include "../../kyber_amd/csrc/kem_kernels.h"
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using P = ky::Par<3>;
+template <int AB> float run(int n, const uint8_t* seeds, int16_t* mat, hipEvent_t a, hipEvent_t b) {
+  int jobs = n * 9;
+  hipEventRecord(a);
+  ky::k_sample_matrix<P, AB><<<(jobs + 255) / 256, 256>>>(jobs, seeds, 32, 1, mat);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms;
+}
+int main() {
+  const int n = 131072;
+  uint8_t* seeds; int16_t* mat;
+  CK(hipMalloc(&seeds, n * 32)); CK(hipMalloc(&mat, (size_t)n * 9 * 512));
+  CK(hipMemset(seeds, 0x3c, n * 32));
+  // distinct seeds: write index into first 4 bytes
+  { std::vector<uint32_t> h(n * 8); for (int i = 0; i < n * 8; i++) h[i] = i * 2654435761u; CK(hipMemcpy(seeds, h.data(), n * 32, hipMemcpyHostToDevice)); }
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int r = 0; r < 4; r++) {
+    float t0 = run<0>(n, seeds, mat, a, b), t1 = run<1>(n, seeds, mat, a, b), t2 = run<2>(n, seeds, mat, a, b);
+    printf("round %d: full %.3f ms | no drain %.3f ms | perm only %.3f ms   (n=%d x 9 entries)\n", r, t0, t1, t2, n);
+  }
+  CK(hipDeviceSynchronize());
+  return 0;
+}
