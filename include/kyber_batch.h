@@ -45,6 +45,9 @@ extern "C" {
 /* parameter-set selector for the generic entry points: k in {2,3,4}
  * (ref/params.h:4-8 KYBER_K), nineties = 1 for the -90s sets (KYBER_90S) */
 
+/* 1 if the parameter set is built into this library, else 0 */
+int kyber_hip_supported(int k, int nineties);
+
 /* object sizes, = ref/params.h:63-66 / ref/api.h:6-9,29-32,52-55; 0 for a bad k */
 size_t kyber_hip_pk_bytes(int k);
 size_t kyber_hip_sk_bytes(int k);

@@ -273,13 +273,15 @@ int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
 
 extern "C" {
 
+int kyber_hip_supported(int k, int nineties) { return (k >= 2 && k <= 4 && !nineties) ? 1 : 0; }
+
 size_t kyber_hip_pk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)384 * k + 32; }
 size_t kyber_hip_sk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)768 * k + 96; }
 size_t kyber_hip_ct_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)32 * ((k == 4 ? 11 : 10) * k + (k == 4 ? 5 : 4)); }
 
 int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, void* stream) {
   if (!pk || !sk || !coins) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, keypair_dev<Par<2>>(n, pk, sk, coins, st), keypair_dev<Par<3>>(n, pk, sk, coins, st),
            keypair_dev<Par<4>>(n, pk, sk, coins, st));
@@ -287,14 +289,14 @@ int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t*
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
                         void* stream) {
   if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, enc_dev<Par<2>>(n, ct, ss, pk, coins, st), enc_dev<Par<3>>(n, ct, ss, pk, coins, st),
            enc_dev<Par<4>>(n, ct, ss, pk, coins, st));
 }
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, dec_dev<Par<2>>(n, ss, ct, sk, st), dec_dev<Par<3>>(n, ss, ct, sk, st),
            dec_dev<Par<4>>(n, ss, ct, sk, st));
@@ -302,19 +304,19 @@ int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_
 
 int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
   if (!pk || !sk) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   DISPATCH(k, nineties, keypair_host<Par<2>>(n, pk, sk, coins), keypair_host<Par<3>>(n, pk, sk, coins),
            keypair_host<Par<4>>(n, pk, sk, coins));
 }
 int kyber_batch_enc(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
   if (!ct || !ss || !pk) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   DISPATCH(k, nineties, enc_host<Par<2>>(n, ct, ss, pk, coins), enc_host<Par<3>>(n, ct, ss, pk, coins),
            enc_host<Par<4>>(n, ct, ss, pk, coins));
 }
 int kyber_batch_dec(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
-  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   DISPATCH(k, nineties, dec_host<Par<2>>(n, ss, ct, sk), dec_host<Par<3>>(n, ss, ct, sk), dec_host<Par<4>>(n, ss, ct, sk));
 }
 

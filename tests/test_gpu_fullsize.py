@@ -1,0 +1,60 @@
+"""GPU: BASELINE.json's full sizes through size-independent properties.
+2^20 Kyber768 instances: decaps(encaps) round trip for every instance, a
+strided sample bit-exact against the oracle, implicit rejection on a corrupted
+subset; 2^20-polynomial NTT round trip."""
+import numpy as np
+import pytest
+import torch
+
+import kyber_amd
+from kyber_amd import lib as kl
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kyber768_one_million_roundtrip(oracle):
+    k, n = 3, 1 << 20
+    kem = kyber_amd.KyberHip(k)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x4B59424552)
+    kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = kem.keypair_dev(kc)
+    ct, ssb = kem.enc_dev(pk, ec)
+    ssa = kem.dec_dev(ct, sk)
+    assert torch.equal(ssa, ssb)
+    assert torch.equal(sk[:, 384 * k:384 * k + kem.pk_bytes], pk)          # sk embeds pk
+    assert torch.equal(sk[:, -32:], kc[:, 32:])                            # z
+    # distinct instances give distinct secrets (sorted-unique over a sample)
+    s = ssb[:: 64].cpu().numpy()
+    assert len({bytes(r) for r in s}) == len(s)
+    idx = torch.arange(0, n, 4099, device="cuda")
+    opk, osk = oracle.keypair(k, kc[idx].cpu().numpy())
+    oct_, oss = oracle.enc(k, opk, ec[idx].cpu().numpy())
+    assert np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk)
+    assert np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssb[idx].cpu().numpy(), oss)
+    # corrupt every 8th ciphertext: those, and only those, must reject
+    bad = ct.clone()
+    bad[::8, 17] ^= 0x01
+    ssr = kem.dec_dev(bad, sk)
+    same = (ssr == ssb).all(dim=1)
+    assert not same[::8].any()
+    mask = torch.ones(n, dtype=torch.bool, device="cuda")
+    mask[::8] = False
+    assert same[mask].all()
+    j = torch.arange(0, n, 8 * 1031, device="cuda")
+    assert np.array_equal(ssr[j].cpu().numpy(), oracle.dec(k, bad[j].cpu().numpy(), sk[j].cpu().numpy()))
+
+
+def test_ntt_roundtrip_one_million_polys():
+    """invntt_tomont(poly_ntt(a)) == a * 2^16 mod q for 2^20 polynomials."""
+    n, Q = 1 << 20, 3329
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    a = torch.randint(0, Q, (n, 256), dtype=torch.int16, device="cuda", generator=g)
+    r = a.clone()
+    kl.poly_ntt_(r)
+    assert int(r.abs().max()) <= Q // 2
+    kl.poly_invntt_(r)
+    want = (a.to(torch.int32) * ((1 << 16) % Q)) % Q
+    assert torch.equal(r.to(torch.int32) % Q, want)
