@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_et
 // three blocks (P ~ 0.8 % each) keep the whole wavefront squeezing.
 constexpr int STAGE_DW = 57;  // dwords per lane: 1 carry slot + 112 candidates + 1 spill
 
-template <int BITOFF>
-__device__ __forceinline__ uint32_t field12(const uint32_t (&H)[42]) {
+template <int BITOFF, int N>
+__device__ __forceinline__ uint32_t field12(const uint32_t (&H)[N]) {
   constexpr int k = BITOFF >> 5, s = BITOFF & 31;
   if constexpr (s == 0) return H[k] & 0xFFFu;
   else if constexpr (s == 20) return H[k] >> 20;
@@ -243,20 +243,50 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 __device__ __forceinline__ void lds_st16(uint32_t addr, uint32_t v) { *(lds_u16*)(uintptr_t)addr = (uint16_t)v; }
 
-template <int G>
-__device__ __forceinline__ void parse_group(const uint32_t (&H)[42], uint32_t& waddr) {
-  uint32_t d1 = field12<24 * G>(H), d2 = field12<24 * G + 12>(H);
+template <int G, int N>
+__device__ __forceinline__ void parse_group(const uint32_t (&H)[N], uint32_t& waddr) {
+  uint32_t d1 = field12<24 * G, N>(H), d2 = field12<24 * G + 12, N>(H);
   lds_st16(waddr, d1);
   waddr += accept_step(d1);
   lds_st16(waddr, d2);
   waddr += accept_step(d2);
 }
-template <int G0, int G1>
-__device__ __forceinline__ void parse_range(const uint32_t (&H)[42], uint32_t& waddr) {
+template <int G0, int G1, int N>
+__device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& waddr) {
   if constexpr (G0 < G1) {
-    parse_group<G0>(H, waddr);
-    parse_range<G0 + 1, G1>(H, waddr);
+    parse_group<G0, N>(H, waddr);
+    parse_range<G0 + 1, G1, N>(H, waddr);
   }
+}
+
+// Drain one parsed chunk of a wavefront's staging tile (rows of SDW dwords, one
+// per lane) into the polynomials mat32[(job0 + p) * 128 ...]: lane p's
+// polynomial gets dwords [c0>>1, (min(c1,256)+1)>>1) of its row.  Eight rows per
+// step, all LDS reads issued before the first store, so the LDS latency is paid
+// once per step instead of once per row.  Then carries an unpaired last
+// coefficient to slot 0 of the row for the next chunk.  Returns the new count.
+template <int SDW>
+__device__ __forceinline__ int drain_tile(uint32_t* tile, int lane, long job0, int c0, int c1, uint32_t* mat32) {
+  const int d0v = c0 >> 1;
+  const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
+#pragma unroll 1
+  for (int p0 = 0; p0 < 64; p0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = tile[(p0 + u) * SDW + lane];
+#pragma unroll
+    for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int d0 = __builtin_amdgcn_readlane(d0v, p0 + u), nd = __builtin_amdgcn_readlane(ndv, p0 + u);
+      if (lane < nd) mat32[(job0 + p0 + u) * 128 + d0 + lane] = v[u];
+    }
+  }
+  if (c0 < 256 && (c1 & 1)) {
+    uint16_t* h = reinterpret_cast<uint16_t*>(tile + lane * SDW);
+    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
+  }
+  return c0 < 256 ? c1 : c0;
 }
 
 template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either)
@@ -295,7 +325,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     const uint32_t w0 = row_addr + 2u * (ctr & 1);
     uint32_t waddr = w0;
     if constexpr (ABLATE < 2) {
-      parse_range<0, 56>(H, waddr);
+      parse_range<0, 56, 42>(H, waddr);
     } else {
 #pragma unroll
       for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
@@ -303,30 +333,8 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     }
     const int c0 = ctr;
     const int c1 = c0 + (int)((waddr - w0) >> 1);
-    // drain: the polynomial of lane p gets dwords [c0>>1, (min(c1,256)+1)>>1) of
-    // its row.  Eight rows per step, all LDS reads issued before the first
-    // store, so the LDS latency is paid once per step instead of once per row.
-    const int d0v = c0 >> 1;
-    const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
-#pragma unroll 1
-    for (int p0 = 0; p0 < (ABLATE ? 0 : 64); p0 += 8) {
-      uint32_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = tile[(p0 + u) * STAGE_DW + lane];
-#pragma unroll
-      for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int d0 = __builtin_amdgcn_readlane(d0v, p0 + u), nd = __builtin_amdgcn_readlane(ndv, p0 + u);
-        if (lane < nd) out32[(job0 + p0 + u) * 128 + d0 + lane] = v[u];
-      }
-    }
-    // carry an unpaired last coefficient to slot 0 for the next block
-    if (c0 < 256 && (c1 & 1)) {
-      uint16_t* h = reinterpret_cast<uint16_t*>(row);
-      h[0] = h[(c0 & 1) + (c1 - c0) - 1];
-    }
-    ctr = c0 < 256 ? c1 : c0;
+    if constexpr (ABLATE == 0) ctr = drain_tile<STAGE_DW>(tile, lane, job0, c0, c1, out32);
+    else ctr = c0 < 256 ? c1 : c0;
   }
 }
 

@@ -1,0 +1,181 @@
+// kem_kernels_90s.h -- the symmetric layer of the -90s parameter sets
+// (ref/symmetric.h:17-32): hash_h/kdf = SHA-256, hash_g = SHA-512, XOF and PRF
+// = AES-256-CTR.  Only the sponge-layout kernels differ from the SHAKE sets;
+// the poly-layout arithmetic kernels of kem_kernels.h consume the same
+// workspace (expanded matrix, raw PRF bytes, 128-byte records) unchanged.
+#pragma once
+#include "kem_kernels.h"
+#include "sha2.h"
+#include "aes.h"
+
+namespace ky {
+
+__device__ __forceinline__ void st32Bv(uint8_t* p, const u64p (&v)[4]) { st32B(p, v[0], v[1], v[2], v[3]); }
+
+// keypair, before: (rho, sigma) = sha512(d).                    ref/indcpa.c:215-216
+__global__ void __launch_bounds__(256) k90_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p d[4], lo[4], hi[4];
+  ld32B(coins + (size_t)i * 64, d);
+  sha512_small<1>(d, d, lo, hi);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32Bv(s, lo);
+  st32Bv(s + 32, hi);
+}
+
+// keypair, after: sk tail = sha256(pk) || z.                       ref/kem.c:30-32
+template <class P>
+__global__ void __launch_bounds__(256) k90_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                   uint8_t* __restrict__ sk) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h[8];
+  u64p hp[4], z[4];
+  sha256_global<P::PKB>(pk + (size_t)i * P::PKB, h);
+  sha256_digest_le(h, hp);
+  uint8_t* tail = sk + (size_t)i * P::SKB + 2 * P::PVB + 32;
+  st32Bv(tail, hp);
+  ld32B(coins + (size_t)i * 64 + 32, z);
+  st32Bv(tail + 32, z);
+}
+
+// encaps, before: m = sha256(m0); (Kbar, r) = sha512(m || sha256(pk)).   ref/kem.c:59-65
+template <class P>
+__global__ void __launch_bounds__(256) k90_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                   uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h[8];
+  u64p m0[4], m[4], hp[4], kb[4], r[4];
+  ld32B(coins + (size_t)i * 32, m0);
+  sha256_32(m0, m);
+  sha256_global<P::PKB>(pk + (size_t)i * P::PKB, h);
+  sha256_digest_le(h, hp);
+  sha512_small<2>(m, hp, kb, r);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32Bv(s, m);
+  st32Bv(s + 32, kb);
+  st32Bv(s + 64, r);
+}
+
+// decaps, middle: (Kbar', r') = sha512(m' || H(pk) from sk).       ref/kem.c:109-111
+template <class P>
+__global__ void __launch_bounds__(256) k90_dec_mid(int n, const uint8_t* __restrict__ sk, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p m[4], hp[4], kb[4], r[4];
+  uint8_t* s = small + (size_t)i * SMALL;
+  ld32B(s, m);
+  ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 32, hp);
+  sha512_small<2>(m, hp, kb, r);
+  st32Bv(s + 32, kb);
+  st32Bv(s + 64, r);
+}
+
+// encaps/decaps, after: ss = sha256(Kbar-or-z || sha256(ct)).      ref/kem.c:71-73, :116-125
+template <class P, bool DEC>
+__global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+                                                const uint8_t* __restrict__ sk, uint8_t* __restrict__ ss) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h[8];
+  u64p hc[4], kb[4], out[4];
+  sha256_global<P::CTB>(ct + (size_t)i * P::CTB, h);
+  sha256_digest_le(h, hc);
+  const uint8_t* s = small + (size_t)i * SMALL;
+  ld32B(s + 32, kb);
+  if constexpr (DEC) {
+    u64p z[4];
+    ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 64, z);
+    uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      kb[w].lo ^= mask & (kb[w].lo ^ z[w].lo);
+      kb[w].hi ^= mask & (kb[w].hi ^ z[w].hi);
+    }
+  }
+  sha256_64(kb, hc, out);
+  st32Bv(ss + (size_t)i * 32, out);
+}
+
+// PRF: AES-256-CTR(key = seed, nonce = {nonce,0,...}) from counter 0.
+// ref/symmetric-aes.c:15-20 -> ref/aes256ctr.c:557-563.  Jobs are nonce-major.
+template <class P>
+__global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+                                               int seed_off, uint8_t* __restrict__ prf) {
+  __shared__ uint32_t tab[AES_TABLE_DW];
+  aes_table_init(tab);
+  const AesLds L = aes_lds(tab);
+  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)n * njobs_per_inst) return;
+  int nonce = (int)(gid / n), inst = (int)(gid % n);
+  u64p key[4];
+  uint32_t rk[60];
+  ld32B(small + (size_t)inst * SMALL + seed_off, key);
+  aes256_expand(L, key, rk);
+  uint8_t* out = prf + ((size_t)inst * njobs_per_inst + nonce) * P::PRF_STRIDE;
+  const int nblk = (P::ETA1 == 3 && nonce < n_eta1) ? 12 : 8;
+#pragma unroll 1
+  for (int b = 0; b < nblk; b++) {
+    uint32_t o[4];
+    aes256ctr_block(L, rk, (uint32_t)nonce, (uint32_t)b, o);
+    *reinterpret_cast<uint4*>(out + 16 * b) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Matrix expansion: AES-256-CTR(key = rho, nonce = {x,y,0,...}) read as one
+// byte stream, three bytes at a time (ref/indcpa.c:124-145,164-192 with
+// ref/symmetric-aes.c:7-13).  The reference squeezes 512 bytes, then 64 at a
+// time carrying buflen % 3 bytes over; that is a continuous parse of the
+// keystream, reproduced here 96 bytes (six AES blocks, 32 three-byte groups)
+// per step so that no group straddles a step.
+constexpr int STAGE90_DW = 33;  // 1 carry slot + 64 candidates + 1 spill, in dwords
+
+template <class P>
+__global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                         int transposed, int16_t* __restrict__ mat) {
+  __shared__ uint32_t tab[AES_TABLE_DW];
+  __shared__ uint32_t stage[4][64 * STAGE90_DW];
+  aes_table_init(tab);
+  const AesLds L = aes_lds(tab);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long job0 = (long)blockIdx.x * 256 + wave * 64;
+  const long job = job0 + lane;
+  const bool valid = job < njobs;
+  const long jc = valid ? job : (long)njobs - 1;
+  const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
+  const int i = e / P::K, j = e % P::K;
+  const uint32_t x = transposed ? i : j, y = transposed ? j : i;
+
+  u64p key[4];
+  uint32_t rk[60];
+  ld32B(rho + (size_t)inst * rho_stride, key);
+  aes256_expand(L, key, rk);
+
+  uint32_t* tile = stage[wave];
+  const uint32_t row_addr = lds_addr(tile + lane * STAGE90_DW);
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
+  int ctr = valid ? 0 : 256;
+  uint32_t blk = 0;
+  while (__any(ctr < 256)) {
+    uint32_t H[24];
+#pragma unroll 1
+    for (int b = 0; b < 6; b++) {
+      uint32_t o[4];
+      aes256ctr_block(L, rk, x | y << 8, blk + b, o);
+      // H[4b..4b+3] = o, with a compile-time destination (b is a run-time loop index)
+#pragma unroll
+      for (int bb = 0; bb < 6; bb++)
+        if (bb == b) { H[4 * bb] = o[0]; H[4 * bb + 1] = o[1]; H[4 * bb + 2] = o[2]; H[4 * bb + 3] = o[3]; }
+    }
+    blk += 6;
+    const uint32_t w0 = row_addr + 2u * (ctr & 1);
+    uint32_t waddr = w0;
+    parse_range<0, 32, 24>(H, waddr);
+    const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
+    ctr = drain_tile<STAGE90_DW>(tile, lane, job0, c0, c1, out32);
+  }
+}
+
+}  // namespace ky

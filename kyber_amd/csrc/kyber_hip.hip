@@ -15,7 +15,7 @@
 
 #include "../../include/kyber_batch.h"
 #include "../../include/kyber_api.h"
-#include "kem_kernels.h"
+#include "kem_kernels_90s.h"
 
 using namespace ky;
 
@@ -122,7 +122,7 @@ inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
   } while (0)
 
 // ---- the three pipelines (device pointers) -----------------------------------
-template <class P>
+template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t chunk = n < g_chunk ? n : g_chunk;
@@ -132,16 +132,29 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
-    RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
-    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    if constexpr (N90) RUN("k90_kp_pre", st, k90_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
+    else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
+    if constexpr (N90) {
+      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
+    } else {
+      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
+    }
+    if constexpr (N90) {
+      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    } else {
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    }
     RUN("k_kp_arith", st, k_kp_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, L.small, L.mat, L.prf, p, s));
-    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
+    if constexpr (N90) {
+      RUN("k90_kp_post", st, k90_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
+    } else {
+      RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
+    }
   }
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t chunk = n < g_chunk ? n : g_chunk;
@@ -151,16 +164,32 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = pk + o * P::PKB;
     uint8_t* c = ct + o * P::CTB;
-    RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
-    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    if constexpr (N90) {
+      RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
+    } else {
+      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
+    }
+    if constexpr (N90) {
+      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
+    } else {
+      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
+    }
+    if constexpr (N90) {
+      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    } else {
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    }
     RUN("k_enc_arith", st, k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, P::PKB, L.small, L.mat, L.prf, c));
-    RUN("k_post", st, k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
+    if constexpr (N90) {
+      RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
+    } else {
+      RUN("k_post", st, k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
+    }
   }
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t chunk = n < g_chunk ? n : g_chunk;
@@ -171,21 +200,41 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStre
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * P::SKB;
     RUN("k_dec_arith", st, k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, L.small));
-    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
-    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    if constexpr (N90) {
+      RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
+    } else {
+      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
+    }
+    if constexpr (N90) {
+      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
+    } else {
+      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
+    }
+    if constexpr (N90) {
+      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    } else {
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    }
     // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
     RUN("k_enc_arith_cmp", st, k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, P::SKB, L.small, L.mat, L.prf,
                                                              const_cast<uint8_t*>(c)));
-    RUN("k_post", st, k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
+    if constexpr (N90) {
+      RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
+    } else {
+      RUN("k_post", st, k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
+    }
   }
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
   if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
-  RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
+  if constexpr (N90) {
+    RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
+  } else {
+    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
+  }
   return 0;
 }
 
@@ -216,20 +265,20 @@ int fill_coins(uint8_t* dst_dev, const uint8_t* coins, size_t bytes) {
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int keypair_host(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
   DevBuf dpk, dsk, dc;
   if (int rc = dpk.alloc(n * P::PKB)) return rc;
   if (int rc = dsk.alloc(n * P::SKB)) return rc;
   if (int rc = dc.alloc(n * 64)) return rc;
   if (int rc = fill_coins(dc.p, coins, n * 64)) return rc;
-  if (int rc = keypair_dev<P>(n, dpk.p, dsk.p, dc.p, nullptr)) return rc;
+  if (int rc = keypair_dev<P, N90>(n, dpk.p, dsk.p, dc.p, nullptr)) return rc;
   HIP_TRY(hipMemcpy(pk, dpk.p, n * P::PKB, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sk, dsk.p, n * P::SKB, hipMemcpyDeviceToHost));
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
   DevBuf dpk, dct, dss, dc;
   if (int rc = dpk.alloc(n * P::PKB)) return rc;
@@ -238,13 +287,13 @@ int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_
   if (int rc = dc.alloc(n * 32)) return rc;
   HIP_TRY(hipMemcpy(dpk.p, pk, n * P::PKB, hipMemcpyHostToDevice));
   if (int rc = fill_coins(dc.p, coins, n * 32)) return rc;
-  if (int rc = enc_dev<P>(n, dct.p, dss.p, dpk.p, dc.p, nullptr)) return rc;
+  if (int rc = enc_dev<P, N90>(n, dct.p, dss.p, dpk.p, dc.p, nullptr)) return rc;
   HIP_TRY(hipMemcpy(ct, dct.p, n * P::CTB, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
   return 0;
 }
 
-template <class P>
+template <class P, bool N90>
 int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
   DevBuf dsk, dct, dss;
   if (int rc = dsk.alloc(n * P::SKB)) return rc;
@@ -252,28 +301,30 @@ int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
   if (int rc = dss.alloc(n * 32)) return rc;
   HIP_TRY(hipMemcpy(dsk.p, sk, n * P::SKB, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dct.p, ct, n * P::CTB, hipMemcpyHostToDevice));
-  if (int rc = dec_dev<P>(n, dss.p, dct.p, dsk.p, nullptr)) return rc;
+  if (int rc = dec_dev<P, N90>(n, dss.p, dct.p, dsk.p, nullptr)) return rc;
   HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
   return 0;
 }
 
 // dispatch on the run-time parameter set
-#define DISPATCH(K, NINETIES, EXPR512, EXPR768, EXPR1024) \
-  do {                                                     \
-    if ((NINETIES)) return KYBER_HIP_ENOSYS;               \
-    switch (K) {                                           \
-      case 2: return EXPR512;                              \
-      case 3: return EXPR768;                              \
-      case 4: return EXPR1024;                             \
-      default: return KYBER_HIP_EINVAL;                    \
-    }                                                      \
+#define DISPATCH(K, NINETIES, FN, ...)                                   \
+  do {                                                                    \
+    switch ((K) * 2 + ((NINETIES) ? 1 : 0)) {                             \
+      case 4: return FN<Par<2>, false>(__VA_ARGS__);                      \
+      case 5: return FN<Par<2>, true>(__VA_ARGS__);                       \
+      case 6: return FN<Par<3>, false>(__VA_ARGS__);                      \
+      case 7: return FN<Par<3>, true>(__VA_ARGS__);                       \
+      case 8: return FN<Par<4>, false>(__VA_ARGS__);                      \
+      case 9: return FN<Par<4>, true>(__VA_ARGS__);                       \
+      default: return KYBER_HIP_EINVAL;                                   \
+    }                                                                     \
   } while (0)
 
 }  // namespace
 
 extern "C" {
 
-int kyber_hip_supported(int k, int nineties) { return (k >= 2 && k <= 4 && !nineties) ? 1 : 0; }
+int kyber_hip_supported(int k, int nineties) { return (k >= 2 && k <= 4 && (nineties == 0 || nineties == 1)) ? 1 : 0; }
 
 size_t kyber_hip_pk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)384 * k + 32; }
 size_t kyber_hip_sk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)768 * k + 96; }
@@ -283,49 +334,43 @@ int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t*
   if (!pk || !sk || !coins) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, keypair_dev<Par<2>>(n, pk, sk, coins, st), keypair_dev<Par<3>>(n, pk, sk, coins, st),
-           keypair_dev<Par<4>>(n, pk, sk, coins, st));
+  DISPATCH(k, nineties, keypair_dev, n, pk, sk, coins, st);
 }
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
                         void* stream) {
   if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, enc_dev<Par<2>>(n, ct, ss, pk, coins, st), enc_dev<Par<3>>(n, ct, ss, pk, coins, st),
-           enc_dev<Par<4>>(n, ct, ss, pk, coins, st));
+  DISPATCH(k, nineties, enc_dev, n, ct, ss, pk, coins, st);
 }
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, dec_dev<Par<2>>(n, ss, ct, sk, st), dec_dev<Par<3>>(n, ss, ct, sk, st),
-           dec_dev<Par<4>>(n, ss, ct, sk, st));
+  DISPATCH(k, nineties, dec_dev, n, ss, ct, sk, st);
 }
 
 int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
   if (!pk || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
-  DISPATCH(k, nineties, keypair_host<Par<2>>(n, pk, sk, coins), keypair_host<Par<3>>(n, pk, sk, coins),
-           keypair_host<Par<4>>(n, pk, sk, coins));
+  DISPATCH(k, nineties, keypair_host, n, pk, sk, coins);
 }
 int kyber_batch_enc(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
   if (!ct || !ss || !pk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
-  DISPATCH(k, nineties, enc_host<Par<2>>(n, ct, ss, pk, coins), enc_host<Par<3>>(n, ct, ss, pk, coins),
-           enc_host<Par<4>>(n, ct, ss, pk, coins));
+  DISPATCH(k, nineties, enc_host, n, ct, ss, pk, coins);
 }
 int kyber_batch_dec(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
-  DISPATCH(k, nineties, dec_host<Par<2>>(n, ss, ct, sk), dec_host<Par<3>>(n, ss, ct, sk), dec_host<Par<4>>(n, ss, ct, sk));
+  DISPATCH(k, nineties, dec_host, n, ss, ct, sk);
 }
 
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, const uint8_t* seeds, int transposed, void* stream) {
   if (!mat || !seeds) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, gen_matrix_dev<Par<2>>(n, mat, seeds, transposed, st),
-           gen_matrix_dev<Par<3>>(n, mat, seeds, transposed, st), gen_matrix_dev<Par<4>>(n, mat, seeds, transposed, st));
+  DISPATCH(k, nineties, gen_matrix_dev, n, mat, seeds, transposed, st);
 }
 
 int kyber_batch_poly_ntt_dev(size_t npoly, int16_t* r, void* stream) {

@@ -13,29 +13,31 @@ def _coins(n, width, seed):
     return np.random.default_rng(seed).integers(0, 256, size=(n, width), dtype=np.uint8)
 
 
+@pytest.mark.parametrize("n90", [0, 1])
 @pytest.mark.parametrize("k", [2, 3, 4])
 @pytest.mark.parametrize("n", [1, 7, 8, 9, 64, 257, 1000])
-def test_kem_matches_oracle(oracle, k, n):
-    kem = kyber_amd.KyberHip(k)
+def test_kem_matches_oracle(oracle, k, n, n90):
+    kem = kyber_amd.KyberHip(k, n90)
     kc, ec = _coins(n, 64, 100 * k + n), _coins(n, 32, 200 * k + n)
     pk, sk = kem.keypair(kc)
-    opk, osk = oracle.keypair(k, kc)
+    opk, osk = oracle.keypair(k, kc, n90)
     assert np.array_equal(pk, opk), "pk differs"
     assert np.array_equal(sk, osk), "sk differs"
     ct, ss = kem.enc(pk, ec)
-    oct_, oss = oracle.enc(k, opk, ec)
+    oct_, oss = oracle.enc(k, opk, ec, n90)
     assert np.array_equal(ct, oct_), "ct differs"
     assert np.array_equal(ss, oss), "ss (enc) differs"
     ss2 = kem.dec(ct, sk)
     assert np.array_equal(ss2, oss), "ss (dec) differs"
 
 
+@pytest.mark.parametrize("n90", [0, 1])
 @pytest.mark.parametrize("k", [2, 3, 4])
-def test_invalid_ciphertext_and_key(oracle, k):
+def test_invalid_ciphertext_and_key(oracle, k, n90):
     """ref/test_kyber.c:34-95: a flipped ciphertext byte or a wrong secret key
     must give the implicit-rejection secret, the same one the oracle derives."""
     n = 96
-    kem = kyber_amd.KyberHip(k)
+    kem = kyber_amd.KyberHip(k, n90)
     kc, ec = _coins(n, 64, 31 + k), _coins(n, 32, 37 + k)
     pk, sk = kem.keypair(kc)
     ct, ss = kem.enc(pk, ec)
@@ -45,9 +47,9 @@ def test_invalid_ciphertext_and_key(oracle, k):
     bad[np.arange(n), pos] ^= rng.integers(1, 256, size=n, dtype=np.uint8)
     bad[::3] = ct[::3]  # keep a third valid so both branches share wavefronts
     got = kem.dec(bad, sk)
-    want = oracle.dec(k, bad, sk)
+    want = oracle.dec(k, bad, sk, n90)
     assert np.array_equal(got, want)
     assert np.array_equal(got[::3], ss[::3])
     assert not np.any(np.all(got[1::3] == ss[1::3], axis=1))
     wrong_sk = _coins(n, sk.shape[1], 41 + k)
-    assert np.array_equal(kem.dec(ct, wrong_sk), oracle.dec(k, ct, wrong_sk))
+    assert np.array_equal(kem.dec(ct, wrong_sk), oracle.dec(k, ct, wrong_sk, n90))

@@ -16,6 +16,18 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def test_gen_matrix_90s_matches_oracle(oracle):
+    """AES-256-CTR XOF (ref/symmetric-aes.c:7-13): continuous stream parse with
+    the reference's 2-byte carry between its 64-byte refills."""
+    for k in (2, 3, 4):
+        n = 40
+        seeds = np.random.default_rng(90 + k).integers(0, 256, (n, 32), dtype=np.uint8)
+        for tr in (0, 1):
+            got = kyber_amd.KyberHip(k, 1).gen_matrix_dev(_dev(seeds), tr).cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(got[i], oracle.gen_matrix(k, seeds[i], tr, 1)[0]), (k, tr, i)
+
+
 @pytest.mark.parametrize("k", [2, 3, 4])
 @pytest.mark.parametrize("transposed", [0, 1])
 def test_gen_matrix_matches_oracle(oracle, k, transposed):
