@@ -26,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-K = 3  # Kyber768
+K = 3  # Kyber768 (the headline workload); --workload switches the set for side measurements
+N90 = 0
+WORKLOADS = {  # name: (k, nineties, compulsory enc+dec bytes, Keccak-f per enc+dec)  SURVEY.md §3.4, §8(d)
+    "kyber512": (2, 0, 4064, 61), "kyber768": (3, 0, 5856, 100), "kyber1024": (4, 0, 7968, 155),
+    "kyber512-90s": (2, 1, 4064, 0), "kyber768-90s": (3, 1, 5856, 0), "kyber1024-90s": (4, 1, 7968, 0),
+}
 SEED0 = 0x4B59424552  # "KYBER", SURVEY.md §8(d)
 
 # algorithmic constants (restated in DESIGN.md)
@@ -50,7 +55,7 @@ def cpu_baseline(budget_s=20.0):
     kind, impl, lib = "port", "oracle", None
     for cand in (("avx2",) if oracle_lib.has_avx2() else ()) + ("ref",):
         try:
-            lib = oracle_lib.RefLib(cand, K)
+            lib = oracle_lib.RefLib(cand, K, N90)
             kind, impl = "reference", cand
             break
         except (OSError, FileNotFoundError):
@@ -59,9 +64,9 @@ def cpu_baseline(budget_s=20.0):
         o = oracle_lib.load_oracle()
 
         class _Port:
-            def keypair(self, c): return o.keypair(K, c)
-            def enc(self, pk, c): return o.enc(K, pk, c)
-            def dec(self, ct, sk): return o.dec(K, ct, sk)
+            def keypair(self, c): return o.keypair(K, c, N90)
+            def enc(self, pk, c): return o.enc(K, pk, c, N90)
+            def dec(self, ct, sk): return o.dec(K, ct, sk, N90)
         lib = _Port()
 
     # calibrate on one core
@@ -93,8 +98,53 @@ def cpu_baseline(budget_s=20.0):
     return {
         "value": threads * per_thread / dt, "unit": "encaps+decaps/s", "cores": threads, "kind": kind,
         "impl": impl, "one_core": one_core,
-        "sample": "Kyber768 enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt),
+        "sample": "enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt),
     }
+
+
+def bench_ntt(args):
+    """BASELINE.json configs[1]: batched forward NTT / basemul / inverse NTT on
+    2^20 polynomials (int16[256]) resident in HBM; one JSON line."""
+    import torch
+    from kyber_amd import lib as kl
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    n = args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED0)
+    a = torch.randint(0, 3329, (n, 256), dtype=torch.int16, device=dev, generator=g)
+    b = torch.randint(0, 3329, (n, 256), dtype=torch.int16, device=dev, generator=g)
+    r = torch.empty_like(a)
+    res = {}
+
+    def timed(name, fn, nbytes):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        res[name] = {"ms": ms, "polys_per_s": n / (ms * 1e-3), "GBps": n * nbytes / (ms * 1e-3) * 1e-9,
+                     "hbm_frac": n * nbytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS}
+
+    work = a.clone()
+    timed("poly_ntt", lambda: kl.poly_ntt_(work), 1024)
+    timed("poly_invntt", lambda: kl.poly_invntt_(work), 1024)
+    timed("poly_basemul", lambda: kl.poly_basemul(r, a, b), 1536)
+    timed("poly_mul_fused(ntt,ntt,basemul,invntt)", lambda: kl.poly_mul_fused(r, a, b), 1536)
+    fwd = res["poly_ntt"]
+    print(json.dumps({
+        "metric": "batched NTTs/sec per GPU", "value": fwd["polys_per_s"], "unit": "NTT/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": fwd["ms"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+        "config": {"workload": "forward NTT (poly_ntt) on %d polynomials of Z_3329[X]/(X^256+1), in place in HBM" % n},
+        "roofline": {"kernel": "k_poly_ntt", "bound": "hbm", "achieved": fwd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": fwd["hbm_frac"], "traffic": None},
+        "kernels": res}), flush=True)
 
 
 def main():
@@ -104,7 +154,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="KEM instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="kyber768", choices=sorted(WORKLOADS) + ["ntt"],
+                    help="default kyber768 = BASELINE.json's metric; others are side measurements")
     args = ap.parse_args()
+    if args.workload == "ntt":
+        return bench_ntt(args)
+    global K, N90, ENCDEC_BYTES, ENCDEC_PERMS
+    K, N90, ENCDEC_BYTES, ENCDEC_PERMS = WORKLOADS[args.workload]
+    set_name = "Kyber%d%s" % (256 * K, "-90s" if N90 else "")
 
     import numpy as np
     import torch
@@ -127,7 +184,7 @@ def main():
         torch.cuda.synchronize()
 
     dev = torch.device("cuda", local)
-    kem = kyber_amd.KyberHip(K)
+    kem = kyber_amd.KyberHip(K, N90)
     n = args.batch
     gen = torch.Generator(device=dev)
     gen.manual_seed(SEED0 + rank)
@@ -163,8 +220,8 @@ def main():
         import oracle_lib
         o = oracle_lib.load_oracle()
         idx = torch.arange(0, n, 4096, device=dev)
-        opk, osk = o.keypair(K, kcoins[idx].cpu().numpy())
-        oct_, oss = o.enc(K, opk, ecoins[idx].cpu().numpy())
+        opk, osk = o.keypair(K, kcoins[idx].cpu().numpy(), N90)
+        oct_, oss = o.enc(K, opk, ecoins[idx].cpu().numpy(), N90)
         parity = bool(np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk)
                       and np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssa[idx].cpu().numpy(), oss))
         assert parity, "strided sample differs from the oracle"
@@ -188,7 +245,7 @@ def main():
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
         chunk = min(n, 1 << 17)
-        if dom == "k_sample_matrix":
+        if dom in ("k_sample_matrix", "k90_sample_matrix"):
             entries = chunk * K * K
             ops = entries * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS
             bytes_ = entries * MATRIX_ENTRY_BYTES
@@ -199,7 +256,7 @@ def main():
         roof = {
             "kernel": dom, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
             "frac": ach / VALU_PEAK_TLOPS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
-            "units_per_launch": chunk * K * K if dom == "k_sample_matrix" else chunk,
+            "units_per_launch": chunk * K * K if dom.endswith("sample_matrix") else chunk,
             "hbm": {"achieved": bytes_ / avg_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes_ / avg_s * 1e-9 / HBM_PEAK_GBS},
         }
@@ -208,17 +265,21 @@ def main():
         total = n * world * args.steps
         value = total / dt
         out = {
-            "metric": "Kyber768 encaps+decaps/sec", "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
+            "metric": "%s encaps+decaps/sec" % set_name, "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16/u64",
             "data": "synthetic (device-generated coins, seed 0x4B59424552)",
-            "config": {"workload": "Kyber768 batched encaps+decaps, %d instances per GPU per step, device-resident" % n,
+            "config": {"workload": "%s batched encaps+decaps, %d instances per GPU per step, device-resident" % (set_name, n),
                        "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective"},
             "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_oracle": parity},
             "pipeline": {"valu_frac": value / world * ENCDEC_PERMS * KECCAK_LANE_OPS * 1e-12 / VALU_PEAK_TLOPS,
                          "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS},
             "roofline": roof, "kernels": kernels,
         }
+        if N90:  # the Keccak lane-op constant does not describe the AES/SHA-2 sets
+            out["pipeline"]["valu_frac"] = None
+            if roof:
+                roof.update({"achieved": None, "frac": None})
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
