@@ -1,0 +1,264 @@
+// fpoly.h -- Z_3329[X]/(X^256+1) arithmetic on the fp32 pipe.
+//
+// Measured on MI355X (profiles/r01_microbench_valu_rate_*.txt): v_fma_f32 /
+// v_mul_f32 / v_add_f32 issue at full rate, while every integer multiply
+// (v_mul_i32_i24, v_mad_i32_i24, v_mul_lo_u32, v_mad_i32_i16) is half rate.
+// All values on this path are integers below 2^24 in magnitude, which fp32
+// represents exactly, so a modular product is
+//     p = a*b              (exact while |a*b| < 2^24)
+//     k = rint(p * (1/q))  (may be off by one near a half; harmless)
+//     r = fma(-k, q, p)    (exact: an integer with |r| <= q/2 + 3)
+// i.e. four full-rate ops instead of a Montgomery product's four half-rate
+// ones, and there is no Montgomery domain at all: coefficients are plain
+// residues, twiddles are 17^brv7(i) mod q, the inverse transform ends with
+// 128^-1.  The bytes the KEM emits are canonical residues (every serializer of
+// the reference canonicalises: ref/poly.c:118-121,28-30,188-190;
+// ref/polyvec.c:24-26), so they do not depend on the representative or on the
+// Montgomery factors the reference carries internally; tests pin that with
+// SHA256SUMS through this path.
+//
+// Magnitude discipline (products must stay below 2^24 = 16.7 M):
+//   |twiddle| <= 1664.  A value that enters a product is kept <= 10 000.
+//   fred() output: |r| <= 1668.  Bounds are stated at each call site.
+//
+// Same 32-work-items-per-polynomial layout and pass structure as poly.h; LDS
+// buffers hold fp32 with an XOR swizzle so that all three access maps are
+// bank-conflict-free.
+#pragma once
+#include "poly.h"
+
+namespace ky {
+
+__constant__ const float ZETAF[128] = KY_ZETAS_PLAIN_INIT;
+
+constexpr float QF = 3329.0f;
+constexpr float QINVF = 1.0f / 3329.0f;
+
+// centred residue of an integer-valued x, |x| < 2^24.  rint() is half rate on
+// gfx950, so the quotient is rounded by adding and subtracting 1.5 * 2^23
+// (three full-rate ops in all).
+constexpr float RND_MAGIC = 12582912.0f;
+__device__ __forceinline__ float fred(float x) {
+  float k = __builtin_fmaf(x, QINVF, RND_MAGIC) - RND_MAGIC;
+  return __builtin_fmaf(k, -QF, x);
+}
+__device__ __forceinline__ float fmm(float a, float b) { return fred(a * b); }
+
+// [0,q) integer of a centred residue (|r| < q)
+__device__ __forceinline__ int fcanon(float r) {
+  int v = (int)r;
+  return v + ((v >> 31) & Q);
+}
+
+// Sub-wavefront rendezvous: the 32 work-items of a polynomial group sit in one
+// wavefront, whose LDS operations are issued and completed in program order,
+// so ordering the compiler is all that is needed.
+#define KY_WSYNC()                                            \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+
+// ---------------------------------------------------------------- LDS maps (fp32, swizzled)
+// element i lives at i ^ ((i >> 5) << 2): STRIDE, MIDDLE and CONTIG accesses
+// then each touch 32 distinct banks per 32-lane group.
+__device__ __forceinline__ void f_put_stride(float* p, int t, const float (&c)[8]) {
+#pragma unroll
+  for (int m = 0; m < 8; m++) p[32 * m + (t ^ (4 * m))] = c[m];
+}
+__device__ __forceinline__ void f_get_stride(const float* p, int t, float (&c)[8]) {
+#pragma unroll
+  for (int m = 0; m < 8; m++) c[m] = p[32 * m + (t ^ (4 * m))];
+}
+__device__ __forceinline__ void f_put_middle(float* p, int t, const float (&c)[8]) {
+  const int hi = t >> 2, base = 32 * hi + (t & 3);
+#pragma unroll
+  for (int m = 0; m < 8; m++) p[base + 4 * (m ^ hi)] = c[m];
+}
+__device__ __forceinline__ void f_get_middle(const float* p, int t, float (&c)[8]) {
+  const int hi = t >> 2, base = 32 * hi + (t & 3);
+#pragma unroll
+  for (int m = 0; m < 8; m++) c[m] = p[base + 4 * (m ^ hi)];
+}
+// coefficients 8t..8t+7: two aligned quads, each moved as a unit by the swizzle
+__device__ __forceinline__ void f_put_contig(float* p, int t, const float (&c)[8]) {
+  const int s = (t >> 2) << 2;
+  *reinterpret_cast<float4*>(p + ((8 * t) ^ s)) = make_float4(c[0], c[1], c[2], c[3]);
+  *reinterpret_cast<float4*>(p + ((8 * t + 4) ^ s)) = make_float4(c[4], c[5], c[6], c[7]);
+}
+__device__ __forceinline__ void f_get_contig(const float* p, int t, float (&c)[8]) {
+  const int s = (t >> 2) << 2;
+  float4 a = *reinterpret_cast<const float4*>(p + ((8 * t) ^ s));
+  float4 b = *reinterpret_cast<const float4*>(p + ((8 * t + 4) ^ s));
+  c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+}
+// unswizzled fp32 polynomial storage that is only ever read CONTIG
+__device__ __forceinline__ void f_put_plain(float* p, int t, const float (&c)[8]) {
+  *reinterpret_cast<float4*>(p + 8 * t) = make_float4(c[0], c[1], c[2], c[3]);
+  *reinterpret_cast<float4*>(p + 8 * t + 4) = make_float4(c[4], c[5], c[6], c[7]);
+}
+__device__ __forceinline__ void f_get_plain(const float* p, int t, float (&c)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p + 8 * t), b = *reinterpret_cast<const float4*>(p + 8 * t + 4);
+  c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+}
+
+// Twiddles indexed per lane come from a 512-byte LDS copy (Z): a constant-memory
+// access with a per-lane index is a vector memory load whose latency would be
+// exposed three times per transform.  Compile-time indices stay on ZETAF
+// (scalar loads).  Call once per workgroup, ends with a barrier.
+__device__ __forceinline__ void f_twiddles_to_lds(float* Z) {
+  if (threadIdx.x < 128) Z[threadIdx.x] = ZETAF[threadIdx.x];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- butterflies
+__device__ __forceinline__ void f_ct(float& a, float& b, float z) {  // Cooley-Tukey, ref/ntt.c:89-91
+  float t = fmm(z, b);
+  b = a - t;
+  a = a + t;
+}
+__device__ __forceinline__ void f_gs(float& a, float& b, float z) {  // Gentleman-Sande, ref/ntt.c:116-119 (sum left unreduced)
+  float t = a;
+  a = t + b;
+  b = fmm(z, b - t);
+}
+
+// ---------------------------------------------------------------- forward NTT
+// in : c[] CONTIG, |c| <= 4095 (noise, decompressed or 12-bit unpacked values)
+// out: c[] CONTIG, centred residues of the plain NTT (= ref/poly.c:244-248 mod q)
+// p  : the group's swizzled fp32 scratch buffer (256 floats)
+// bounds: each layer adds <= 1668, so 4095 -> 9099 after three layers (products
+// <= 1664 * 7431 = 12.4 M); reduce; 1668 -> 6672 after three more (products
+// <= 8.4 M); last layer multiplies values <= 6672 (11.2 M).
+__device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float (&c)[8]) {
+  KY_WSYNC();
+  f_put_contig(p, t, c);
+  KY_WSYNC();
+  f_get_stride(p, t, c);
+#pragma unroll
+  for (int m = 0; m < 4; m++) f_ct(c[m], c[m + 4], ZETAF[1]);
+  f_ct(c[0], c[2], ZETAF[2]); f_ct(c[1], c[3], ZETAF[2]);
+  f_ct(c[4], c[6], ZETAF[3]); f_ct(c[5], c[7], ZETAF[3]);
+  f_ct(c[0], c[1], ZETAF[4]); f_ct(c[2], c[3], ZETAF[5]);
+  f_ct(c[4], c[5], ZETAF[6]); f_ct(c[6], c[7], ZETAF[7]);
+#pragma unroll
+  for (int m = 0; m < 8; m++) c[m] = fred(c[m]);
+  KY_WSYNC();
+  f_put_stride(p, t, c);
+  KY_WSYNC();
+  f_get_middle(p, t, c);
+  {
+    const int hi = t >> 2;
+    float z = Z[8 + hi];
+#pragma unroll
+    for (int m = 0; m < 4; m++) f_ct(c[m], c[m + 4], z);
+    float z0 = Z[16 + 2 * hi], z1 = Z[17 + 2 * hi];
+    f_ct(c[0], c[2], z0); f_ct(c[1], c[3], z0);
+    f_ct(c[4], c[6], z1); f_ct(c[5], c[7], z1);
+    f_ct(c[0], c[1], Z[32 + 4 * hi]); f_ct(c[2], c[3], Z[33 + 4 * hi]);
+    f_ct(c[4], c[5], Z[34 + 4 * hi]); f_ct(c[6], c[7], Z[35 + 4 * hi]);
+  }
+  KY_WSYNC();
+  f_put_middle(p, t, c);
+  KY_WSYNC();
+  f_get_contig(p, t, c);
+  {
+    float z0 = Z[64 + 2 * t], z1 = Z[65 + 2 * t];
+    f_ct(c[0], c[2], z0); f_ct(c[1], c[3], z0);
+    f_ct(c[4], c[6], z1); f_ct(c[5], c[7], z1);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = fred(c[k]);
+}
+
+// ---------------------------------------------------------------- inverse NTT
+// in : c[] CONTIG, |c| <= 1668 (NTT domain)
+// out: c[] CONTIG, centred residues of the plain inverse NTT (no Montgomery
+//      factor: it replaces invntt_tomont applied to a basemul result, whose
+//      2^-16 and 2^16 cancel in the reference, ref/ntt.c:106-126)
+// bounds: sums double per layer and are reduced every second layer, so a
+// difference entering a product is <= 2 * 3336 = 6672 (11.2 M).
+__device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float (&c)[8]) {
+  {
+    float z0 = Z[127 - 2 * t], z1 = Z[126 - 2 * t];
+    f_gs(c[0], c[2], z0); f_gs(c[1], c[3], z0);
+    f_gs(c[4], c[6], z1); f_gs(c[5], c[7], z1);
+  }
+  KY_WSYNC();
+  f_put_contig(p, t, c);
+  KY_WSYNC();
+  f_get_middle(p, t, c);
+  {
+    const int hi = t >> 2;
+    f_gs(c[0], c[1], Z[63 - 4 * hi]); f_gs(c[2], c[3], Z[62 - 4 * hi]);
+    f_gs(c[4], c[5], Z[61 - 4 * hi]); f_gs(c[6], c[7], Z[60 - 4 * hi]);
+    c[0] = fred(c[0]); c[2] = fred(c[2]); c[4] = fred(c[4]); c[6] = fred(c[6]);  // sums of two layers
+    float za = Z[31 - 2 * hi], zb = Z[30 - 2 * hi];
+    f_gs(c[0], c[2], za); f_gs(c[1], c[3], za);
+    f_gs(c[4], c[6], zb); f_gs(c[5], c[7], zb);
+    float z = Z[15 - hi];
+#pragma unroll
+    for (int m = 0; m < 4; m++) f_gs(c[m], c[m + 4], z);
+    c[0] = fred(c[0]); c[1] = fred(c[1]); c[2] = fred(c[2]); c[3] = fred(c[3]);
+  }
+  KY_WSYNC();
+  f_put_middle(p, t, c);
+  KY_WSYNC();
+  f_get_stride(p, t, c);
+  f_gs(c[0], c[1], ZETAF[7]); f_gs(c[2], c[3], ZETAF[6]);
+  f_gs(c[4], c[5], ZETAF[5]); f_gs(c[6], c[7], ZETAF[4]);
+  f_gs(c[0], c[2], ZETAF[3]); f_gs(c[1], c[3], ZETAF[3]);
+  f_gs(c[4], c[6], ZETAF[2]); f_gs(c[5], c[7], ZETAF[2]);
+  c[0] = fred(c[0]); c[1] = fred(c[1]); c[4] = fred(c[4]); c[5] = fred(c[5]);
+#pragma unroll
+  for (int m = 0; m < 4; m++) f_gs(c[m], c[m + 4], ZETAF[1]);
+#pragma unroll
+  for (int m = 0; m < 8; m++) c[m] = fmm(c[m], KY_NINV_PLAIN);  // |c| <= 3336, * 26
+  KY_WSYNC();
+  f_put_stride(p, t, c);
+  KY_WSYNC();
+  f_get_contig(p, t, c);
+}
+
+// ---------------------------------------------------------------- basemul
+// acc[] += a[] o b[] (plain product in Z_q[X]/(X^2 -+ zeta)), each term reduced
+// before it is added: |a| <= 4095 (matrix entries, unpacked key bytes),
+// |b| <= 1668 (NTT output), so a single product is <= 6.9 M and a two-product
+// sum <= 13.7 M.  ref/ntt.c:139-146, ref/poly.c:273-280, ref/polyvec.c:194-198.
+__device__ __forceinline__ void f_basemul_acc(float (&acc)[8], const float (&a)[8], const float (&b)[8], const float* Z, int t) {
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const float z = Z[64 + 2 * t + g];
+    const int o = 4 * g;
+    float h0 = fmm(a[o + 1], b[o + 1]), h1 = fmm(a[o + 3], b[o + 3]);
+    acc[o + 0] += fred(__builtin_fmaf(h0, z, a[o + 0] * b[o + 0]));
+    acc[o + 1] += fred(__builtin_fmaf(a[o + 0], b[o + 1], a[o + 1] * b[o + 0]));
+    acc[o + 2] += fred(__builtin_fmaf(h1, -z, a[o + 2] * b[o + 2]));
+    acc[o + 3] += fred(__builtin_fmaf(a[o + 2], b[o + 3], a[o + 3] * b[o + 2]));
+  }
+}
+
+// compact persistent storage: centred residues as int16, CONTIG access only
+__device__ __forceinline__ void f_put_i16(int16_t* p, int t, const float (&c)[8]) {
+  int v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = (int)c[k];
+  lds_put_contig(p, t, v);
+}
+__device__ __forceinline__ void f_get_i16(const int16_t* p, int t, float (&c)[8]) {
+  int v[8];
+  lds_get_contig(p, t, v);
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = (float)v[k];
+}
+
+__device__ __forceinline__ void i2f8(const int (&c)[8], float (&f)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) f[k] = (float)c[k];
+}
+__device__ __forceinline__ void f2canon8(const float (&f)[8], int (&c)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = fcanon(f[k]);
+}
+
+}  // namespace ky

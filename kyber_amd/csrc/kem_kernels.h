@@ -18,6 +18,7 @@
 #pragma once
 #include "keccak.h"
 #include "poly.h"
+#include "fpoly.h"
 
 namespace ky {
 
@@ -348,8 +349,30 @@ __device__ __forceinline__ void ld_coef8(const int16_t* p, int t, int (&c)[8]) {
   unpack8(*reinterpret_cast<const uint4*>(p + 8 * t), c);
 }
 
+// The three arithmetic kernels below run on the fp32 engine of fpoly.h (plain
+// residues, no Montgomery domain).  What they write -- pk, sk, ct, m' -- are
+// canonical byte strings, identical to the reference's.
+
+__device__ __forceinline__ void ld_coef8f(const int16_t* p, int t, float (&f)[8]) {
+  int c[8];
+  ld_coef8(p, t, c);
+  i2f8(c, f);
+}
+__device__ __forceinline__ void ld_bytes12f(const uint8_t* p, int t, float (&f)[8]) {
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(p) + 3 * t;
+  int c[8];
+  frombytes12(s[0], s[1], s[2], c);
+  i2f8(c, f);
+}
+__device__ __forceinline__ void st_bytes12(uint8_t* p, int t, const int (&c)[8]) {
+  uint32_t w0, w1, w2;
+  tobytes12(c, w0, w1, w2);
+  uint32_t* o = reinterpret_cast<uint32_t*>(p) + 3 * t;
+  o[0] = w0; o[1] = w1; o[2] = w2;
+}
+
 // ------------------------------------------------------------------ keypair arithmetic
-// ref/indcpa.c:220-238: s,e <- CBD(PRF); s^,e^ = NTT; t^ = A s^ (tomont) + e^;
+// ref/indcpa.c:220-238: s,e <- CBD(PRF); s^,e^ = NTT; t^ = A s^ + e^;
 // pk = tobytes(t^) || rho ; sk = tobytes(s^) (|| pk copy, ref/kem.c:28-29)
 template <class P>
 __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
@@ -357,52 +380,44 @@ __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restri
                                                   uint8_t* __restrict__ sk) {
   constexpr int K = P::K;
   __shared__ __attribute__((aligned(16))) int16_t se[G_INST][2 * K][256];  // s^ then e^
-  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
 
   for (int q = w.g; q < G_INST * 2 * K; q += 8) {
     const int li = q / (2 * K), v = q % (2 * K);
     const int gi = min(inst0 + li, n - 1);
     int c[8];
+    float f[8];
     cbd_contig<P::ETA1>(prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE, w.t, c);
-    KY_GSYNC();
-    lds_put_contig(wk[w.g], w.t, c);
-    KY_GSYNC();
-    ntt_fwd(wk[w.g], w.t, c);
-    lds_put_contig(se[li][v], w.t, c);
+    i2f8(c, f);
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    f_put_i16(se[li][v], w.t, f);
     if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
-      uint32_t w0, w1, w2;
-      tobytes12(c, w0, w1, w2);
-      uint32_t* o = reinterpret_cast<uint32_t*>(sk + (size_t)gi * P::SKB + 384 * v) + 3 * w.t;
-      o[0] = w0; o[1] = w1; o[2] = w2;
+      f2canon8(f, c);
+      st_bytes12(sk + (size_t)gi * P::SKB + 384 * v, w.t, c);
     }
   }
-  KY_GSYNC();
+  __syncthreads();
   for (int q = w.g; q < G_INST * K; q += 8) {
     const int li = q / K, i = q % K;
     const int gi = min(inst0 + li, n - 1);
-    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      ld_coef8(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
-      lds_get_contig(se[li][j], w.t, b);
-      basemul_acc(acc, a, b, w.t);
+      ld_coef8f(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
+      f_get_i16(se[li][j], w.t, b);
+      f_basemul_acc(acc, a, b, ztab, w.t);
     }
-    lds_get_contig(se[li][K + i], w.t, b);
+    f_get_i16(se[li][K + i], w.t, b);
+    int c[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      int r = barrett(acc[k]);                  // ref/polyvec.c:200
-      r = mont_reduce(r * 1353);                // poly_tomont, ref/poly.c:290-296
-      acc[k] = barrett(r + b[k]);               // + e^, reduce   ref/indcpa.c:234-235
-    }
+    for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + b[k]));  // + e^   ref/indcpa.c:234-235
     if (inst0 + li < n) {
-      uint32_t w0, w1, w2;
-      tobytes12(acc, w0, w1, w2);
-      uint32_t* o = reinterpret_cast<uint32_t*>(pk + (size_t)gi * P::PKB + 384 * i) + 3 * w.t;
-      o[0] = w0; o[1] = w1; o[2] = w2;
-      uint32_t* o2 = reinterpret_cast<uint32_t*>(sk + (size_t)gi * P::SKB + P::PVB + 384 * i) + 3 * w.t;
-      o2[0] = w0; o2[1] = w1; o2[2] = w2;
+      st_bytes12(pk + (size_t)gi * P::PKB + 384 * i, w.t, c);
+      st_bytes12(sk + (size_t)gi * P::SKB + P::PVB + 384 * i, w.t, c);
     }
   }
   // rho -> pk tail and its copy inside sk
@@ -427,11 +442,13 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
                                                    const uint8_t* __restrict__ prf, uint8_t* __restrict__ ct) {
   constexpr int K = P::K, NJ = 2 * K + 1;
   __shared__ __attribute__((aligned(16))) int16_t sp[G_INST][K][256];
-  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
   __shared__ uint32_t bad[G_INST];
+  __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
   if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
 
   // r^ = NTT(CBD_eta1(PRF(r, j)))
@@ -439,47 +456,43 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
     const int li = q / K, j = q % K;
     const int gi = min(inst0 + li, n - 1);
     int c[8];
+    float f[8];
     cbd_contig<P::ETA1>(prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE, w.t, c);
-    KY_GSYNC();
-    lds_put_contig(wk[w.g], w.t, c);
-    KY_GSYNC();
-    ntt_fwd(wk[w.g], w.t, c);
-    lds_put_contig(sp[li][j], w.t, c);
+    i2f8(c, f);
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    f_put_i16(sp[li][j], w.t, f);
   }
-  KY_GSYNC();
+  __syncthreads();
   // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
   for (int q = w.g; q < G_INST * (K + 1); q += 8) {
     const int li = q / (K + 1), i = q % (K + 1);
     const int gi = min(inst0 + li, n - 1);
-    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      if (i < K) {
-        ld_coef8(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
-      } else {
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
-        frombytes12(s[0], s[1], s[2], a);
-      }
-      lds_get_contig(sp[li][j], w.t, b);
-      basemul_acc(acc, a, b, w.t);
+      if (i < K) ld_coef8f(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
+      else ld_bytes12f(pk + (size_t)gi * pk_stride + 384 * j, w.t, a);
+      f_get_i16(sp[li][j], w.t, b);
+      f_basemul_acc(acc, a, b, ztab, w.t);
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
-    ntt_inv(wk[w.g], w.t, acc);
-    stride_to_contig(wk[w.g], w.t, acc);
-    cbd_contig<2>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE, w.t, b);  // nonce K+i (i==K: 2K)
+    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+    f_ntt_inv(wk[w.g], ztab, w.t, acc);
+    int e[8], c[8];
+    cbd_contig<2>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE, w.t, e);  // nonce K+i (i==K: 2K)
     if (i < K) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k] + b[k]);
-      compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, acc);
+      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)e[k]));
+      compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
     } else {
-      frommsg_contig(small[(size_t)gi * SMALL + w.t], a);
+      int m[8];
+      frommsg_contig(small[(size_t)gi * SMALL + w.t], m);
 #pragma unroll
-      for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k] + b[k] + a[k]);
-      compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, acc);
+      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)(e[k] + m[k])));
+      compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
     }
   }
-  KY_GSYNC();
+  __syncthreads();
   // the workgroup's ciphertexts are one contiguous run of global memory
   const int nvalid = min(G_INST, n - inst0);
   const uint4* src = reinterpret_cast<const uint4*>(&ctb[0][0]);
@@ -493,7 +506,7 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
     }
   }
   if constexpr (CMP) {
-    KY_GSYNC();
+    __syncthreads();
     if (threadIdx.x < nvalid)
       *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + threadIdx.x) * SMALL + 96) = bad[threadIdx.x];
   }
@@ -506,41 +519,41 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
                                                    uint8_t* __restrict__ small) {
   constexpr int K = P::K;
   __shared__ __attribute__((aligned(16))) int16_t uh[G_INST][K][256];
-  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
 
   for (int q = w.g; q < G_INST * K; q += 8) {
     const int li = q / K, j = q % K;
     const int gi = min(inst0 + li, n - 1);
     int c[8];
+    float f[8];
     decompress_contig<P::DU>(ct + (size_t)gi * P::CTB + P::UB * j, w.t, c);
-    KY_GSYNC();
-    lds_put_contig(wk[w.g], w.t, c);
-    KY_GSYNC();
-    ntt_fwd(wk[w.g], w.t, c);
-    lds_put_contig(uh[li][j], w.t, c);
+    i2f8(c, f);
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    f_put_i16(uh[li][j], w.t, f);
   }
-  KY_GSYNC();
+  __syncthreads();
   {
     const int li = w.g;  // G_INST == number of groups: one result polynomial each
     const int gi = min(inst0 + li, n - 1);
-    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      const uint32_t* s = reinterpret_cast<const uint32_t*>(sk + (size_t)gi * P::SKB + 384 * j) + 3 * w.t;
-      frombytes12(s[0], s[1], s[2], a);
-      lds_get_contig(uh[li][j], w.t, b);
-      basemul_acc(acc, a, b, w.t);
+      ld_bytes12f(sk + (size_t)gi * P::SKB + 384 * j, w.t, a);
+      f_get_i16(uh[li][j], w.t, b);
+      f_basemul_acc(acc, a, b, ztab, w.t);
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
-    ntt_inv(wk[w.g], w.t, acc);
-    stride_to_contig(wk[w.g], w.t, acc);
-    decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, b);
+    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+    f_ntt_inv(wk[w.g], ztab, w.t, acc);
+    int v[8], c[8];
+    decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, v);
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = barrett(b[k] - acc[k]);
-    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)tomsg_contig(acc);
+    for (int k = 0; k < 8; k++) c[k] = fcanon(fred((float)v[k] - acc[k]));
+    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)tomsg_contig(c);
   }
 }
 

@@ -123,11 +123,32 @@ KERNEL(k_mbcnt, A_MBCNT)
 KERNEL(k_dot2, A_DOT2)
 KERNEL(k_dot4, A_DOT4)
 
+#define A_FMUL(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_FADD(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define A_FFMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_FMAC(n) "v_fmac_f32 %" #n ", %8, %9\n"
+#define A_RNDNE(n) "v_rndne_f32 %" #n ", %" #n "\n"
+#define A_CVTFI(n) "v_cvt_f32_i32 %" #n ", %" #n "\n"
+#define A_CVTIF(n) "v_cvt_i32_f32 %" #n ", %" #n "\n"
+#define A_FLOOR(n) "v_floor_f32 %" #n ", %" #n "\n"
+#define A_FRACT(n) "v_fract_f32 %" #n ", %" #n "\n"
+KERNEL(k_fmul, A_FMUL)
+KERNEL(k_fadd, A_FADD)
+KERNEL(k_ffma, A_FFMA)
+KERNEL(k_fmac, A_FMAC)
+KERNEL(k_rndne, A_RNDNE)
+KERNEL(k_cvtfi, A_CVTFI)
+KERNEL(k_cvtif, A_CVTIF)
+KERNEL(k_floor, A_FLOOR)
+KERNEL(k_fract, A_FRACT)
+
 typedef void (*kfn)(uint32_t*, unsigned long long*, int);
 struct V { const char* name; kfn f; };
 
 int main() {
-  V vs[] = {{"v_xor_b32(e32)", k_xor}, {"v_xor_b32(e64)", k_xor_e64}, {"v_bitop3 0x96", k_bitop3}, {"v_bitop3 0xd2", k_bitop3d2},
+  V vs[] = {{"v_mul_f32", k_fmul}, {"v_add_f32", k_fadd}, {"v_fma_f32", k_ffma}, {"v_fmac_f32", k_fmac}, {"v_rndne_f32", k_rndne},
+            {"v_cvt_f32_i32", k_cvtfi}, {"v_cvt_i32_f32", k_cvtif}, {"v_floor_f32", k_floor}, {"v_fract_f32", k_fract},
+            {"v_xor_b32(e32)", k_xor}, {"v_xor_b32(e64)", k_xor_e64}, {"v_bitop3 0x96", k_bitop3}, {"v_bitop3 0xd2", k_bitop3d2},
             {"v_alignbit", k_alignbit}, {"v_bfi", k_bfi}, {"v_or3", k_or3}, {"v_mul_i32_i24", k_muli24}, {"v_mad_i32_i24", k_madi24},
             {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_i32", k_mulhi}, {"v_mad_i32_i16", k_madi16}, {"v_pk_add_i16", k_pkadd},
             {"v_pk_mul_lo_u16", k_pkmul}, {"v_add_u32", k_add}, {"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd},
