@@ -451,45 +451,93 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
   f_twiddles_to_lds(ztab);
   if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
 
+  // Global operands are fetched one loop iteration ahead of their use: each
+  // iteration's dependent chain (LDS transposes inside the transforms) is long
+  // enough to hide an HBM round trip that would otherwise be paid in full at
+  // 3-4 waves per SIMD.
+
   // r^ = NTT(CBD_eta1(PRF(r, j)))
-  for (int q = w.g; q < G_INST * K; q += 8) {
-    const int li = q / K, j = q % K;
-    const int gi = min(inst0 + li, n - 1);
-    int c[8];
-    float f[8];
-    cbd_contig<P::ETA1>(prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE, w.t, c);
-    i2f8(c, f);
-    f_ntt_fwd(wk[w.g], ztab, w.t, f);
-    f_put_i16(sp[li][j], w.t, f);
+  {
+    auto fetch = [&](int q, uint32_t (&r)[3]) {
+      const int li = q / K, j = q % K;
+      const int gi = min(inst0 + li, n - 1);
+      const uint8_t* b = prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE;
+      if constexpr (P::ETA1 == 2) {
+        r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+      } else {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
+        r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+      }
+    };
+    uint32_t nxt[3] = {0, 0, 0};
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * K; q += 8) {
+      const int li = q / K, j = q % K;
+      uint32_t cur[3] = {nxt[0], nxt[1], nxt[2]};
+      if (q + 8 < G_INST * K) fetch(q + 8, nxt);
+      int c[8];
+      float f[8];
+      if constexpr (P::ETA1 == 2) cbd2_word(cur[0], c);
+      else cbd3_words(cur[0] | (cur[1] & 0xFFu) << 16, (cur[1] >> 8) | cur[2] << 8, c);
+      i2f8(c, f);
+      f_ntt_fwd(wk[w.g], ztab, w.t, f);
+      f_put_i16(sp[li][j], w.t, f);
+    }
   }
   __syncthreads();
   // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
-  for (int q = w.g; q < G_INST * (K + 1); q += 8) {
-    const int li = q / (K + 1), i = q % (K + 1);
-    const int gi = min(inst0 + li, n - 1);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+  {
+    struct Ops {
+      uint4 a[K];          // matrix row entries (8 int16) or 12 key bytes in x,y,z
+      uint32_t noise, msg; // PRF word for CBD2; message byte (row K only)
+    };
+    auto fetch = [&](int q, Ops& o) {
+      const int li = q / (K + 1), i = q % (K + 1);
+      const int gi = min(inst0 + li, n - 1);
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      if (i < K) ld_coef8f(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
-      else ld_bytes12f(pk + (size_t)gi * pk_stride + 384 * j, w.t, a);
-      f_get_i16(sp[li][j], w.t, b);
-      f_basemul_acc(acc, a, b, ztab, w.t);
-    }
+      for (int j = 0; j < K; j++) {
+        if (i < K) {
+          o.a[j] = *reinterpret_cast<const uint4*>(mat + ((size_t)gi * P::NMAT + i * K + j) * 256 + 8 * w.t);
+        } else {
+          const uint32_t* sb = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
+          o.a[j] = make_uint4(sb[0], sb[1], sb[2], 0u);
+        }
+      }
+      o.noise = *reinterpret_cast<const uint32_t*>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE + 4 * w.t);  // nonce K+i
+      o.msg = (i == K) ? small[(size_t)gi * SMALL + w.t] : 0u;
+    };
+    Ops nxt;
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * (K + 1); q += 8) {
+      const int li = q / (K + 1), i = q % (K + 1);
+      Ops cur = nxt;
+      if (q + 8 < G_INST * (K + 1)) fetch(q + 8, nxt);
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
-    f_ntt_inv(wk[w.g], ztab, w.t, acc);
-    int e[8], c[8];
-    cbd_contig<2>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE, w.t, e);  // nonce K+i (i==K: 2K)
-    if (i < K) {
+      for (int j = 0; j < K; j++) {
+        int ai[8];
+        if (i < K) unpack8(cur.a[j], ai);
+        else frombytes12(cur.a[j].x, cur.a[j].y, cur.a[j].z, ai);
+        i2f8(ai, a);
+        f_get_i16(sp[li][j], w.t, b);
+        f_basemul_acc(acc, a, b, ztab, w.t);
+      }
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)e[k]));
-      compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
-    } else {
-      int m[8];
-      frommsg_contig(small[(size_t)gi * SMALL + w.t], m);
+      for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+      f_ntt_inv(wk[w.g], ztab, w.t, acc);
+      int e[8], c[8];
+      cbd2_word(cur.noise, e);
+      if (i < K) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)(e[k] + m[k])));
-      compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
+        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)e[k]));
+        compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
+      } else {
+        int m[8];
+        frommsg_contig(cur.msg, m);
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)(e[k] + m[k])));
+        compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
+      }
     }
   }
   __syncthreads();
