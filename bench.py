@@ -44,6 +44,27 @@ MATRIX_ENTRY_PERMS = 3           # SHAKE128 blocks per matrix entry (4th block: 
 MATRIX_ENTRY_BYTES = 512 + 32 / 9.0
 
 
+def pmc_traffic(kernel, k, chunk):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass
+    (profiles/rNN_pmc_traffic.json, written by tools/pmc_pass.sh +
+    tools/pmc_summarize.py --traffic-json: separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
+    Counters cannot be read from inside this process, so the figure is the
+    recorded one for the same launch size, or None."""
+    import glob
+    if chunk != 1 << 17:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if name.startswith("ky::%s<ky::Par<%d>" % (kernel, k)):
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(budget_s=20.0):
     """Time the reference's own code (oracle/_ref, built from /root/reference's
     ref/ and avx2/ sources) on the host cores; falls back to the oracle port."""
@@ -253,9 +274,11 @@ def main():
             ops = chunk * ENCDEC_PERMS * KECCAK_LANE_OPS
             bytes_ = chunk * ENCDEC_BYTES
         ach = ops / avg_s * 1e-12
+        traffic, traffic_src = pmc_traffic(dom, K, chunk)
         roof = {
             "kernel": dom, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
-            "frac": ach / VALU_PEAK_TLOPS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
+            "frac": ach / VALU_PEAK_TLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": bytes_, "avg_launch_ms": avg_s * 1e3,
             "units_per_launch": chunk * K * K if dom.endswith("sample_matrix") else chunk,
             "hbm": {"achieved": bytes_ / avg_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes_ / avg_s * 1e-9 / HBM_PEAK_GBS},
