@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_et
 // then the wavefront drains the tile row by row so that every global store is
 // a contiguous run of one polynomial.  Lanes that still miss coefficients after
 // three blocks (P ~ 0.8 % each) keep the whole wavefront squeezing.
-constexpr int STAGE_DW = 57;  // dwords per lane: 1 carry slot + 112 candidates + 1 spill
+constexpr int STAGE_DW = 57;  // whole-block row: 1 carry slot + 112 candidates + 1 spill (drain_tile)
 
 template <int BITOFF, int N>
 __device__ __forceinline__ uint32_t field12(const uint32_t (&H)[N]) {
@@ -290,10 +290,51 @@ __device__ __forceinline__ int drain_tile(uint32_t* tile, int lane, long job0, i
   return c0 < 256 ? c1 : c0;
 }
 
+// Same for a tile whose rows hold at most 32 dwords: each half of the wavefront
+// drains its own row, so one store instruction covers two polynomials.
+template <int SDW>
+__device__ __forceinline__ int drain_tile2(uint32_t* tile, int lane, long job0, int c0, int c1, uint32_t* mat32) {
+  static_assert(SDW <= 32, "a row must fit half a wavefront");
+  const int d0v = c0 >> 1;
+  const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
+  const uint32_t meta = (uint32_t)d0v | (uint32_t)ndv << 16;
+  const int l = lane & 31, hi = lane & 32;  // rows p (lanes 0..31) and p + 32 (lanes 32..63)
+  const uint32_t* src = tile + hi * SDW + l;
+  uint32_t* dst = mat32 + (job0 + hi) * 128 + l;
+#pragma unroll 1
+  for (int p0 = 0; p0 < 32; p0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = src[(p0 + u) * SDW];
+#pragma unroll
+    for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t mlo = __builtin_amdgcn_readlane(meta, p0 + u), mhi = __builtin_amdgcn_readlane(meta, p0 + u + 32);
+      const uint32_t m = hi ? mhi : mlo;
+      if (l < (int)(m >> 16)) dst[(p0 + u) * 128 + (m & 0xFFFFu)] = v[u];
+    }
+  }
+  if (c0 < 256 && (c1 & 1)) {
+    uint16_t* h = reinterpret_cast<uint16_t*>(tile + lane * SDW);
+    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
+  }
+  return c0 < 256 ? c1 : c0;
+}
+
+// A 168-byte block is parsed and drained in MAT_PARTS parts, so the staging row
+// of a lane holds 1 carry slot + 112/MAT_PARTS candidates + 1 spill slot.  Two
+// parts: 29 dwords per lane, 29 KB per workgroup, five workgroups per CU (the
+// whole-block tile of 57 dwords allowed two and left the drain's store latency
+// exposed).
+constexpr int MAT_PARTS = 2;
+constexpr int MAT_GROUPS = 56 / MAT_PARTS;          // 3-byte groups per part
+constexpr int MAT_STAGE_DW = (2 * MAT_GROUPS + 2) / 2;
+
 template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either)
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                        int transposed, int16_t* __restrict__ mat) {
-  __shared__ uint32_t stage[4][64 * STAGE_DW];
+  __shared__ uint32_t stage[4][64 * MAT_STAGE_DW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long job0 = (long)blockIdx.x * 256 + wave * 64;  // first job of this wavefront
   const long job = job0 + lane;
@@ -311,7 +352,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   A[4].lo = x | y << 8 | 0x1F0000u;  // rho || x || y || pad    ref/symmetric-shake.c:25-29
   A[20].hi = 0x80000000u;
 
-  uint32_t* row = stage[wave] + lane * STAGE_DW;
+  uint32_t* row = stage[wave] + lane * MAT_STAGE_DW;
   const uint32_t row_addr = lds_addr(row);
   uint32_t* tile = stage[wave];
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
@@ -322,20 +363,25 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     uint32_t H[42];
 #pragma unroll
     for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
-    // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
-    const uint32_t w0 = row_addr + 2u * (ctr & 1);
-    uint32_t waddr = w0;
-    if constexpr (ABLATE < 2) {
-      parse_range<0, 56, 42>(H, waddr);
-    } else {
+    auto part = [&](auto first) {
+      constexpr int G0 = decltype(first)::value;
+      // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
+      const uint32_t w0 = row_addr + 2u * (ctr & 1);
+      uint32_t waddr = w0;
+      if constexpr (ABLATE < 2) {
+        parse_range<G0, G0 + MAT_GROUPS, 42>(H, waddr);
+      } else {
 #pragma unroll
-      for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
-      waddr += 2 * 91;
-    }
-    const int c0 = ctr;
-    const int c1 = c0 + (int)((waddr - w0) >> 1);
-    if constexpr (ABLATE == 0) ctr = drain_tile<STAGE_DW>(tile, lane, job0, c0, c1, out32);
-    else ctr = c0 < 256 ? c1 : c0;
+        for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
+        waddr += 2 * (91 / MAT_PARTS);
+      }
+      const int c0 = ctr;
+      const int c1 = c0 + (int)((waddr - w0) >> 1);
+      if constexpr (ABLATE == 0) ctr = drain_tile2<MAT_STAGE_DW>(tile, lane, job0, c0, c1, out32);
+      else ctr = c0 < 256 ? c1 : c0;
+    };
+    part(std::integral_constant<int, 0>{});
+    if constexpr (MAT_PARTS == 2) part(std::integral_constant<int, MAT_GROUPS>{});
   }
 }
 
