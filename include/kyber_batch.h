@@ -104,6 +104,11 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, cons
 /* ---- housekeeping ---- */
 /* instances processed per internal pass (workspace sizing); 0 restores the default */
 int kyber_hip_set_chunk(size_t instances);
+/* Tuning/test aid (no counterpart in the reference): upper bound on the records
+ * of the matrix sampler's tail queue per pass.  Entries that do not fit are
+ * finished by the main kernel itself, so any value gives the same output;
+ * (size_t)-1 restores the default (1/16 of the entries + 64). */
+int kyber_hip_set_tail_capacity(size_t records);
 /* release the current device's workspace */
 int kyber_hip_release(void);
 /* text of the last HIP error seen by this thread ("" if none) */

@@ -331,9 +331,29 @@ constexpr int MAT_PARTS = 2;
 constexpr int MAT_GROUPS = 56 / MAT_PARTS;          // 3-byte groups per part
 constexpr int MAT_STAGE_DW = (2 * MAT_GROUPS + 2) / 2;
 
+// Tail queue: dword 0 = number of records pushed (may exceed the capacity),
+// records of 64 dwords from dword 64: sponge state (50), entry index, count.
+constexpr int MAT_MAIN_BLOCKS = 3;
+constexpr int TAILQ_HDR_DW = 64, TAILQ_REC_DW = 64;
+__host__ __device__ constexpr size_t tailq_capacity(size_t entries) { return entries / 16 + 64; }
+__host__ __device__ constexpr size_t tailq_bytes(size_t entries) {
+  return 4 * (TAILQ_HDR_DW + tailq_capacity(entries) * TAILQ_REC_DW);
+}
+
+template <int G>
+__device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out, int& ctr) {
+  if constexpr (G < 56) {
+    const uint32_t d1 = field12<24 * G, 42>(H), d2 = field12<24 * G + 12, 42>(H);
+    if (d1 < (uint32_t)Q && ctr < 256) out[ctr++] = (int16_t)d1;
+    if (d2 < (uint32_t)Q && ctr < 256) out[ctr++] = (int16_t)d2;
+    tail_parse<G + 1>(H, out, ctr);
+  }
+}
+
 template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either)
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
-                                                       int transposed, int16_t* __restrict__ mat) {
+                                                       int transposed, int16_t* __restrict__ mat,
+                                                       uint32_t* __restrict__ tailq, uint32_t tail_cap) {
   __shared__ uint32_t stage[4][64 * MAT_STAGE_DW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long job0 = (long)blockIdx.x * 256 + wave * 64;  // first job of this wavefront
@@ -357,6 +377,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   uint32_t* tile = stage[wave];
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
   int ctr = valid ? 0 : 256;
+  int blk = 0;
 
   while (__any(ctr < 256)) {
     keccak_f1600(A);
@@ -382,6 +403,52 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     };
     part(std::integral_constant<int, 0>{});
     if constexpr (MAT_PARTS == 2) part(std::integral_constant<int, MAT_GROUPS>{});
+    // Three blocks complete 99.1 % of the entries, but 41 % of the wavefronts
+    // hold at least one that is still short.  Those entries park their sponge in
+    // the tail queue (k_sample_matrix_tail finishes them, densely packed) instead
+    // of keeping 64 lanes squeezing for one; a full queue just leaves them here.
+    if (++blk == MAT_MAIN_BLOCKS && tailq != nullptr && ctr < 256) {
+      const uint32_t slot = atomicAdd(tailq, 1u);
+      if (slot < tail_cap) {
+        uint32_t* r = tailq + TAILQ_HDR_DW + (size_t)slot * TAILQ_REC_DW;
+#pragma unroll
+        for (int w = 0; w < 24; w += 2)
+          *reinterpret_cast<uint4*>(r + 2 * w) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
+        *reinterpret_cast<uint4*>(r + 48) = make_uint4(A[24].lo, A[24].hi, (uint32_t)job, (uint32_t)ctr);
+        ctr = 256;
+      }
+    }
+  }
+}
+
+// Finishes the entries parked by k_sample_matrix: one work-item per queue
+// record, continues the SHAKE128 stream from the saved sponge and appends
+// accepted candidates to the polynomial in place (coefficients below the saved
+// count are already in memory).  ~1 % of the entries, a handful of
+// coefficients each, so the scattered 2-byte stores do not matter.
+__global__ void __launch_bounds__(64) k_sample_matrix_tail(const uint32_t* __restrict__ tailq, uint32_t tail_cap,
+                                                           int16_t* __restrict__ mat) {
+  const uint32_t cnt = min(tailq[0], tail_cap);
+  const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= cnt) return;
+  const uint32_t* r = tailq + TAILQ_HDR_DW + (size_t)id * TAILQ_REC_DW;
+  u64p A[25];
+#pragma unroll
+  for (int w = 0; w < 24; w += 2) {
+    const uint4 v = *reinterpret_cast<const uint4*>(r + 2 * w);
+    A[w] = u64p{v.x, v.y};
+    A[w + 1] = u64p{v.z, v.w};
+  }
+  const uint4 last = *reinterpret_cast<const uint4*>(r + 48);
+  A[24] = u64p{last.x, last.y};
+  int16_t* out = mat + (size_t)last.z * 256;
+  int ctr = (int)last.w;
+  while (ctr < 256) {
+    keccak_f1600(A);
+    uint32_t H[42];
+#pragma unroll
+    for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
+    tail_parse<0>(H, out, ctr);
   }
 }
 

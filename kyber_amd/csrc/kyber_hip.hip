@@ -42,6 +42,7 @@ struct Workspace {
 };
 Workspace g_ws[MAX_DEV];
 size_t g_chunk = DEFAULT_CHUNK;
+size_t g_tail_cap_max = (size_t)-1;
 std::mutex g_mu;
 
 int ws_reserve(size_t bytes, uint8_t** out) {
@@ -71,16 +72,27 @@ struct Layout {
   int16_t* mat;
   uint8_t* prf;
   uint8_t* small;
+  uint32_t* tailq;  // k_sample_matrix's queue of unfinished entries
+  uint32_t tail_cap;
   int carve(size_t chunk) {
     uint8_t* b;
-    int rc = ws_reserve(chunk * PER, &b);
+    int rc = ws_reserve(chunk * PER + tailq_bytes(chunk * P::NMAT), &b);
     if (rc) return rc;
     mat = reinterpret_cast<int16_t*>(b);
     prf = b + chunk * MAT;
     small = prf + chunk * PRF;
+    tailq = reinterpret_cast<uint32_t*>(small + chunk * SMALL);
+    const size_t cap = tailq_capacity(chunk * P::NMAT);
+    tail_cap = (uint32_t)(cap < g_tail_cap_max ? cap : g_tail_cap_max);
     return 0;
   }
 };
+
+// SHAKE128 matrix expansion: the main pass gives every entry three blocks, the
+// tail pass finishes the ~1 % that need more.
+template <class P>
+int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, uint32_t* tailq,
+                  uint32_t tail_cap, hipStream_t st);
 
 inline unsigned blocks(size_t items, unsigned per) { return (unsigned)((items + per - 1) / per); }
 
@@ -121,6 +133,16 @@ inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
     prof_end(name, st, ev_a_);    \
   } while (0)
 
+template <class P>
+int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, uint32_t* tailq,
+                  uint32_t tail_cap, hipStream_t st) {
+  HIP_TRY(hipMemsetAsync(tailq, 0, sizeof(uint32_t), st));
+  RUN("k_sample_matrix", st,
+      k_sample_matrix<P><<<blocks((size_t)entries, 256), 256, 0, st>>>(entries, rho, rho_stride, transposed, mat, tailq, tail_cap));
+  if (tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(tail_cap, 64), 64, 0, st>>>(tailq, tail_cap, mat));
+  return 0;
+}
+
 // ---- the three pipelines (device pointers) -----------------------------------
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
@@ -137,7 +159,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     if constexpr (N90) {
       RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
     } else {
-      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
+      if (int rc = sample_matrix<P>(m * P::NMAT, L.small, SMALL, 0, L.mat, L.tailq, L.tail_cap, st)) return rc;
     }
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
@@ -172,7 +194,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t
     if constexpr (N90) {
       RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
     } else {
-      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
+      if (int rc = sample_matrix<P>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat, L.tailq, L.tail_cap, st)) return rc;
     }
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
@@ -208,7 +230,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStre
     if constexpr (N90) {
       RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
     } else {
-      RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
+      if (int rc = sample_matrix<P>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat, L.tailq, L.tail_cap, st)) return rc;
     }
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
@@ -233,7 +255,9 @@ int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed,
   if constexpr (N90) {
     RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
   } else {
-    RUN("k_sample_matrix", st, k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
+    // no workspace here: a null queue keeps every entry in the main kernel until it is complete
+    RUN("k_sample_matrix", st,
+        k_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat, nullptr, 0u));
   }
   return 0;
 }
@@ -401,6 +425,12 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, c
 int kyber_hip_set_chunk(size_t instances) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_chunk = instances ? instances : DEFAULT_CHUNK;
+  return 0;
+}
+
+int kyber_hip_set_tail_capacity(size_t records) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_tail_cap_max = records;
   return 0;
 }
 

@@ -66,6 +66,7 @@ def library():
         "kyber_batch_poly_basemul_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_batch_poly_mul_fused_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_hip_set_chunk": [sz],
+        "kyber_hip_set_tail_capacity": [sz],
         "kyber_hip_profile_enable": [ci],
         "kyber_hip_profile_read": [ctypes.c_char_p, sz],
         "kyber_hip_release": [],
@@ -222,6 +223,12 @@ def profile_read():
 
 def set_chunk(instances):
     _check(library().kyber_hip_set_chunk(int(instances)), "kyber_hip_set_chunk")
+
+
+def set_tail_capacity(records=None):
+    """Bound the matrix sampler's tail queue (None = default); output never changes."""
+    v = (1 << 64) - 1 if records is None else int(records)
+    _check(library().kyber_hip_set_tail_capacity(v), "kyber_hip_set_tail_capacity")
 
 
 # ---- batched polynomial kernels on torch int16 tensors [npoly, 256] ----

@@ -53,3 +53,26 @@ def test_invalid_ciphertext_and_key(oracle, k, n90):
     assert not np.any(np.all(got[1::3] == ss[1::3], axis=1))
     wrong_sk = _coins(n, sk.shape[1], 41 + k)
     assert np.array_equal(kem.dec(ct, wrong_sk), oracle.dec(k, ct, wrong_sk, n90))
+
+
+@pytest.mark.parametrize("cap", [0, 5, None])
+def test_matrix_tail_queue_capacity(oracle, cap):
+    """The matrix sampler parks entries that need a 4th SHAKE128 block (about
+    1 % of them: ~80 of the 9000 here) in a queue for a second kernel; entries
+    that do not fit the queue are finished in place.  Every capacity, none
+    included, must give the reference's bytes (ref/indcpa.c:164-192)."""
+    from kyber_amd import lib as kl
+    k, n = 3, 1000
+    kem = kyber_amd.KyberHip(k)
+    kc, ec = _coins(n, 64, 77), _coins(n, 32, 78)
+    try:
+        kl.set_tail_capacity(cap)
+        pk, sk = kem.keypair(kc)
+        ct, ss = kem.enc(pk, ec)
+        ss2 = kem.dec(ct, sk)
+    finally:
+        kl.set_tail_capacity(None)
+    opk, osk = oracle.keypair(k, kc)
+    oct_, oss = oracle.enc(k, opk, ec)
+    assert np.array_equal(pk, opk) and np.array_equal(sk, osk)
+    assert np.array_equal(ct, oct_) and np.array_equal(ss, oss) and np.array_equal(ss2, oss)

@@ -8,7 +8,7 @@ using P = ky::Par<3>;
 template <int AB> float run(int n, const uint8_t* seeds, int16_t* mat, hipEvent_t a, hipEvent_t b) {
   int jobs = n * 9;
   hipEventRecord(a);
-  ky::k_sample_matrix<P, AB><<<(jobs + 255) / 256, 256>>>(jobs, seeds, 32, 1, mat);
+  ky::k_sample_matrix<P, AB><<<(jobs + 255) / 256, 256>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms;
