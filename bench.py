@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="KEM instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shared-key", action="store_true",
+                    help="side measurement: every instance uses ONE key pair (kyber_batch_enc_shared_pk / dec_shared_sk)")
     ap.add_argument("--workload", default="kyber768", choices=sorted(WORKLOADS) + ["ntt"],
                     help="default kyber768 = BASELINE.json's metric; others are side measurements")
     args = ap.parse_args()
@@ -211,14 +213,19 @@ def main():
     gen.manual_seed(SEED0 + rank)
     kcoins = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device=dev, generator=gen)
     ecoins = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=gen)
-    pk, sk = kem.keypair_dev(kcoins)
+    pk, sk = kem.keypair_dev(kcoins[:1] if args.shared_key else kcoins)
     ct = torch.empty((n, kem.ct_bytes), dtype=torch.uint8, device=dev)
     ssb = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     ssa = torch.empty((n, 32), dtype=torch.uint8, device=dev)
 
-    def step():
-        kem.enc_dev(pk, ecoins, ct, ssb)
-        kem.dec_dev(ct, sk, ssa)
+    if args.shared_key:
+        def step():
+            kem.enc_shared_pk_dev(pk[0], ecoins, ct, ssb)
+            kem.dec_shared_sk_dev(ct, sk[0], ssa)
+    else:
+        def step():
+            kem.enc_dev(pk, ecoins, ct, ssb)
+            kem.dec_dev(ct, sk, ssa)
 
     for _ in range(args.warmup):
         step()
@@ -241,9 +248,10 @@ def main():
         import oracle_lib
         o = oracle_lib.load_oracle()
         idx = torch.arange(0, n, 4096, device=dev)
-        opk, osk = o.keypair(K, kcoins[idx].cpu().numpy(), N90)
+        kidx = torch.zeros_like(idx) if args.shared_key else idx
+        opk, osk = o.keypair(K, kcoins[kidx].cpu().numpy(), N90)
         oct_, oss = o.enc(K, opk, ecoins[idx].cpu().numpy(), N90)
-        parity = bool(np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk)
+        parity = bool(np.array_equal(pk[kidx].cpu().numpy(), opk) and np.array_equal(sk[kidx].cpu().numpy(), osk)
                       and np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssa[idx].cpu().numpy(), oss))
         assert parity, "strided sample differs from the oracle"
     except (OSError, ImportError):
@@ -288,11 +296,12 @@ def main():
         total = n * world * args.steps
         value = total / dt
         out = {
-            "metric": "%s encaps+decaps/sec" % set_name, "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
+            "metric": "%s encaps+decaps/sec%s" % (set_name, " (one shared key pair)" if args.shared_key else ""), "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16/u64",
             "data": "synthetic (device-generated coins, seed 0x4B59424552)",
-            "config": {"workload": "%s batched encaps+decaps, %d instances per GPU per step, device-resident" % (set_name, n),
+            "config": {"workload": "%s batched encaps+decaps%s, %d instances per GPU per step, device-resident"
+                       % (set_name, " with one shared key pair" if args.shared_key else "", n),
                        "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective"},
             "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_oracle": parity},
             "pipeline": {"valu_frac": value / world * ENCDEC_PERMS * KECCAK_LANE_OPS * 1e-12 / VALU_PEAK_TLOPS,

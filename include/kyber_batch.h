@@ -73,6 +73,21 @@ int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t *pk, uint8_t 
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, void *stream);
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
 
+/* ---- server-shaped variants: one key, many operations ----
+ * enc_shared_pk: n encapsulations to ONE public key `pk` (KYBER_PUBLICKEYBYTES
+ * bytes), e.g. n clients' worth of ciphertexts for one static server key.
+ * dec_shared_sk: n ciphertexts decapsulated with ONE secret key `sk`.
+ * Both write exactly what kyber_batch_enc / kyber_batch_dec write when given n
+ * copies of the key (n x crypto_kem_enc / crypto_kem_dec, ref/kem.c:51,94);
+ * internally H(pk) (ref/kem.c:64) and the matrix A^T (ref/indcpa.c:268-270)
+ * are computed once instead of n times.  Same argument rules and error codes
+ * as the per-key entry points; *_dev take device pointers and a hipStream_t. */
+int kyber_batch_enc_shared_pk(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins);
+int kyber_batch_dec_shared_sk(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);
+int kyber_batch_enc_shared_pk_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins,
+                                  void *stream);
+int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
+
 /* per-set spellings, e.g. kyber768_batch_enc(n, ct, ss, pk, coins) */
 #define KYBER_HIP_DECLARE_SET(NAME)                                                                         \
   int NAME##_batch_keypair(size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins);                       \

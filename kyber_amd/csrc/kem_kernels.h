@@ -113,10 +113,20 @@ __global__ void __launch_bounds__(256) k_kp_post(int n, const uint8_t* __restric
   st32B(tail + 32, z[0], z[1], z[2], z[3]);
 }
 
+// H(pk) of one key, for the shared-key entry points.
+template <class P>
+__global__ void __launch_bounds__(64) k_hash_pk(const uint8_t* __restrict__ pk, uint8_t* __restrict__ out) {
+  if (threadIdx.x | blockIdx.x) return;
+  u64p A[25];
+  keccak_absorb_words<136, 0x06, P::PKB>(A, pk);
+  st32B(out, A[0], A[1], A[2], A[3]);
+}
+
 // encaps, before: m = H(m0); (Kbar, r) = G(m || H(pk)).         ref/kem.c:59-65
+// hpk != null: every instance uses that one precomputed H(pk) (shared key).
 template <class P>
 __global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
-                                                 uint8_t* __restrict__ small) {
+                                                 const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
@@ -124,9 +134,13 @@ __global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restric
   sha3_256_32(A, m);
 #pragma unroll
   for (int w = 0; w < 4; w++) m[w] = A[w];
-  keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
+  if (hpk != nullptr) {
+    ld32B(hpk, h);
+  } else {
+    keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
 #pragma unroll
-  for (int w = 0; w < 4; w++) h[w] = A[w];
+    for (int w = 0; w < 4; w++) h[w] = A[w];
+  }
   sha3_512_64(A, m, h);
   uint8_t* s = small + (size_t)i * SMALL;
   st32B(s, m[0], m[1], m[2], m[3]);
@@ -136,13 +150,14 @@ __global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restric
 
 // decaps, middle: (Kbar', r') = G(m' || H(pk) from sk).          ref/kem.c:109-111
 template <class P>
-__global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restrict__ sk, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
+                                                 uint8_t* __restrict__ small) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   uint8_t* s = small + (size_t)i * SMALL;
   ld32B(s, m);
-  ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 32, h);
+  ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 32, h);
   sha3_512_64(A, m, h);
   st32B(s + 32, A[0], A[1], A[2], A[3]);
   st32B(s + 64, A[4], A[5], A[6], A[7]);
@@ -151,7 +166,7 @@ __global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restric
 // encaps/decaps, after: ss = KDF(Kbar-or-z || H(ct)).            ref/kem.c:71-73, :116-125
 template <class P, bool DEC>
 __global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
-                                              const uint8_t* __restrict__ sk, uint8_t* __restrict__ ss) {
+                                              const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   u64p A[25], kb[4], h[4];
@@ -163,7 +178,7 @@ __global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__
   if constexpr (DEC) {
     // constant-time select as ref/verify.c:40-47: kb ^= mask & (kb ^ z)
     u64p z[4];
-    ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 64, z);
+    ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 64, z);
     uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -552,6 +567,7 @@ __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restri
 template <class P, bool CMP>
 __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
                                                    uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
+                                                   size_t mat_stride,  // int16 per instance; 0 = one matrix for all
                                                    const uint8_t* __restrict__ prf, uint8_t* __restrict__ ct) {
   constexpr int K = P::K, NJ = 2 * K + 1;
   __shared__ __attribute__((aligned(16))) int16_t sp[G_INST][K][256];
@@ -610,7 +626,7 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
 #pragma unroll
       for (int j = 0; j < K; j++) {
         if (i < K) {
-          o.a[j] = *reinterpret_cast<const uint4*>(mat + ((size_t)gi * P::NMAT + i * K + j) * 256 + 8 * w.t);
+          o.a[j] = *reinterpret_cast<const uint4*>(mat + (size_t)gi * mat_stride + (i * K + j) * 256 + 8 * w.t);
         } else {
           const uint32_t* sb = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
           o.a[j] = make_uint4(sb[0], sb[1], sb[2], 0u);
@@ -677,7 +693,7 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
 // ref/indcpa.c:318-328: m' = tomsg(v - invntt(s^ . NTT(decompress(u))))
 template <class P>
 __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
-                                                   uint8_t* __restrict__ small) {
+                                                   size_t sk_stride, uint8_t* __restrict__ small) {
   constexpr int K = P::K;
   __shared__ __attribute__((aligned(16))) int16_t uh[G_INST][K][256];
   __shared__ __attribute__((aligned(16))) float wk[8][256];
@@ -703,7 +719,7 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      ld_bytes12f(sk + (size_t)gi * P::SKB + 384 * j, w.t, a);
+      ld_bytes12f(sk + (size_t)gi * sk_stride + 384 * j, w.t, a);
       f_get_i16(uh[li][j], w.t, b);
       f_basemul_acc(acc, a, b, ztab, w.t);
     }

@@ -40,18 +40,34 @@ __global__ void __launch_bounds__(256) k90_kp_post(int n, const uint8_t* __restr
   st32Bv(tail + 32, z);
 }
 
+// sha256(pk) of one key, for the shared-key entry points.
+template <class P>
+__global__ void __launch_bounds__(64) k90_hash_pk(const uint8_t* __restrict__ pk, uint8_t* __restrict__ out) {
+  if (threadIdx.x | blockIdx.x) return;
+  uint32_t h[8];
+  u64p hp[4];
+  sha256_global<P::PKB>(pk, h);
+  sha256_digest_le(h, hp);
+  st32Bv(out, hp);
+}
+
 // encaps, before: m = sha256(m0); (Kbar, r) = sha512(m || sha256(pk)).   ref/kem.c:59-65
+// hpk != null: every instance uses that one precomputed sha256(pk) (shared key).
 template <class P>
 __global__ void __launch_bounds__(256) k90_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
-                                                   uint8_t* __restrict__ small) {
+                                                   const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t h[8];
   u64p m0[4], m[4], hp[4], kb[4], r[4];
   ld32B(coins + (size_t)i * 32, m0);
   sha256_32(m0, m);
-  sha256_global<P::PKB>(pk + (size_t)i * P::PKB, h);
-  sha256_digest_le(h, hp);
+  if (hpk != nullptr) {
+    ld32B(hpk, hp);
+  } else {
+    sha256_global<P::PKB>(pk + (size_t)i * P::PKB, h);
+    sha256_digest_le(h, hp);
+  }
   sha512_small<2>(m, hp, kb, r);
   uint8_t* s = small + (size_t)i * SMALL;
   st32Bv(s, m);
@@ -61,13 +77,14 @@ __global__ void __launch_bounds__(256) k90_enc_pre(int n, const uint8_t* __restr
 
 // decaps, middle: (Kbar', r') = sha512(m' || H(pk) from sk).       ref/kem.c:109-111
 template <class P>
-__global__ void __launch_bounds__(256) k90_dec_mid(int n, const uint8_t* __restrict__ sk, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(256) k90_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
+                                                   uint8_t* __restrict__ small) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   u64p m[4], hp[4], kb[4], r[4];
   uint8_t* s = small + (size_t)i * SMALL;
   ld32B(s, m);
-  ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 32, hp);
+  ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 32, hp);
   sha512_small<2>(m, hp, kb, r);
   st32Bv(s + 32, kb);
   st32Bv(s + 64, r);
@@ -76,7 +93,7 @@ __global__ void __launch_bounds__(256) k90_dec_mid(int n, const uint8_t* __restr
 // encaps/decaps, after: ss = sha256(Kbar-or-z || sha256(ct)).      ref/kem.c:71-73, :116-125
 template <class P, bool DEC>
 __global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
-                                                const uint8_t* __restrict__ sk, uint8_t* __restrict__ ss) {
+                                                const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t h[8];
@@ -87,7 +104,7 @@ __global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict
   ld32B(s + 32, kb);
   if constexpr (DEC) {
     u64p z[4];
-    ld32B(sk + (size_t)i * P::SKB + 2 * P::PVB + 64, z);
+    ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 64, z);
     uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
 #pragma unroll
     for (int w = 0; w < 4; w++) {

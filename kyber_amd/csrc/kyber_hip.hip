@@ -74,14 +74,19 @@ struct Layout {
   uint8_t* small;
   uint32_t* tailq;  // k_sample_matrix's queue of unfinished entries
   uint32_t tail_cap;
+  int16_t* smat;    // shared-key calls: the one expanded matrix
+  uint8_t* hpk;     // shared-key calls: H(pk)
   int carve(size_t chunk) {
     uint8_t* b;
-    int rc = ws_reserve(chunk * PER + tailq_bytes(chunk * P::NMAT), &b);
+    const size_t tq = (tailq_bytes(chunk * P::NMAT) + 255) & ~(size_t)255;
+    int rc = ws_reserve(chunk * PER + tq + MAT + 256, &b);
     if (rc) return rc;
     mat = reinterpret_cast<int16_t*>(b);
     prf = b + chunk * MAT;
     small = prf + chunk * PRF;
     tailq = reinterpret_cast<uint32_t*>(small + chunk * SMALL);
+    smat = reinterpret_cast<int16_t*>(small + chunk * SMALL + tq);
+    hpk = reinterpret_cast<uint8_t*>(smat) + MAT;
     const size_t cap = tailq_capacity(chunk * P::NMAT);
     tail_cap = (uint32_t)(cap < g_tail_cap_max ? cap : g_tail_cap_max);
     return 0;
@@ -143,6 +148,18 @@ int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transp
   return 0;
 }
 
+// Matrix expansion for `insts` instances (SHAKE128 or AES-256-CTR XOF), Aᵀ when transposed.
+template <class P, bool N90>
+int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, Layout<P>& L, hipStream_t st) {
+  const int entries = insts * P::NMAT;
+  if constexpr (N90) {
+    RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)entries, 256), 256, 0, st>>>(entries, rho, rho_stride, transposed, mat));
+    return 0;
+  } else {
+    return sample_matrix<P>(entries, rho, rho_stride, transposed, mat, L.tailq, L.tail_cap, st);
+  }
+}
+
 // ---- the three pipelines (device pointers) -----------------------------------
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
@@ -156,11 +173,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
     if constexpr (N90) RUN("k90_kp_pre", st, k90_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
     else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
-    if constexpr (N90) {
-      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, L.small, SMALL, 0, L.mat));
-    } else {
-      if (int rc = sample_matrix<P>(m * P::NMAT, L.small, SMALL, 0, L.mat, L.tailq, L.tail_cap, st)) return rc;
-    }
+    if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     } else {
@@ -176,74 +189,88 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
   return 0;
 }
 
+// Encapsulation.  pk_stride == PKB: n keys (ref/kem.c:51-76 n times);
+// pk_stride == 0: n encapsulations to ONE key -- H(pk) and the matrix are
+// computed once and shared; the bytes written are the same as
+// with n copies of the key.
 template <class P, bool N90>
-int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, hipStream_t st) {
+int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t chunk = n < g_chunk ? n : g_chunk;
+  const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
+  if (shared) {
+    if constexpr (N90) RUN("k90_hash_pk", st, k90_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
+    else RUN("k_hash_pk", st, k_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
+    if (int rc = expand_matrix<P, N90>(1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
+  }
+  const uint8_t* hpk = shared ? L.hpk : nullptr;
+  const int16_t* mat = shared ? L.smat : L.mat;
+  const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
-    const uint8_t* p = pk + o * P::PKB;
+    const uint8_t* p = pk + o * pk_stride;
     uint8_t* c = ct + o * P::CTB;
     if constexpr (N90) {
-      RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
+      RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     } else {
-      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small));
+      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     }
-    if constexpr (N90) {
-      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat));
-    } else {
-      if (int rc = sample_matrix<P>(m * P::NMAT, p + P::PVB, P::PKB, 1, L.mat, L.tailq, L.tail_cap, st)) return rc;
-    }
+    if (!shared)
+      if (int rc = expand_matrix<P, N90>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
-    RUN("k_enc_arith", st, k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, P::PKB, L.small, L.mat, L.prf, c));
+    RUN("k_enc_arith", st, k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, pk_stride, L.small, mat, mat_stride, L.prf, c));
     if constexpr (N90) {
-      RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
+      RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, ss + o * 32));
+      RUN("k_post", st, k_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     }
   }
   return 0;
 }
 
+// Decapsulation.  sk_stride == SKB: n keys (ref/kem.c:94-127 n times);
+// sk_stride == 0: n ciphertexts for ONE secret key, matrix expanded once.
 template <class P, bool N90>
-int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
+int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t chunk = n < g_chunk ? n : g_chunk;
+  const bool shared = sk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
+  if (shared)
+    if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
+  const int16_t* mat = shared ? L.smat : L.mat;
+  const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
-    const uint8_t* s = sk + o * P::SKB;
-    RUN("k_dec_arith", st, k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, L.small));
+    const uint8_t* s = sk + o * sk_stride;
+    RUN("k_dec_arith", st, k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, sk_stride, L.small));
     if constexpr (N90) {
-      RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
+      RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
-      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, L.small));
+      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     }
-    if constexpr (N90) {
-      RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)m * P::NMAT, 256), 256, 0, st>>>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat));
-    } else {
-      if (int rc = sample_matrix<P>(m * P::NMAT, s + 2 * P::PVB, P::SKB, 1, L.mat, L.tailq, L.tail_cap, st)) return rc;
-    }
+    if (!shared)
+      if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
     // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
-    RUN("k_enc_arith_cmp", st, k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, P::SKB, L.small, L.mat, L.prf,
-                                                             const_cast<uint8_t*>(c)));
+    RUN("k_enc_arith_cmp", st, k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, sk_stride, L.small, mat, mat_stride,
+                                                             L.prf, const_cast<uint8_t*>(c)));
     if constexpr (N90) {
-      RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
+      RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, ss + o * 32));
+      RUN("k_post", st, k_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     }
   }
   return 0;
@@ -303,29 +330,48 @@ int keypair_host(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
 }
 
 template <class P, bool N90>
-int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
+int enc_each_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, hipStream_t st) {
+  return enc_dev<P, N90>(n, ct, ss, pk, P::PKB, coins, st);
+}
+template <class P, bool N90>
+int enc_shared_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, hipStream_t st) {
+  return enc_dev<P, N90>(n, ct, ss, pk, 0, coins, st);
+}
+template <class P, bool N90>
+int dec_each_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
+  return dec_dev<P, N90>(n, ss, ct, sk, P::SKB, st);
+}
+template <class P, bool N90>
+int dec_shared_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
+  return dec_dev<P, N90>(n, ss, ct, sk, 0, st);
+}
+
+template <class P, bool N90>
+int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, bool shared) {
   DevBuf dpk, dct, dss, dc;
-  if (int rc = dpk.alloc(n * P::PKB)) return rc;
+  const size_t nkeys = shared ? 1 : n;
+  if (int rc = dpk.alloc(nkeys * P::PKB)) return rc;
   if (int rc = dct.alloc(n * P::CTB)) return rc;
   if (int rc = dss.alloc(n * 32)) return rc;
   if (int rc = dc.alloc(n * 32)) return rc;
-  HIP_TRY(hipMemcpy(dpk.p, pk, n * P::PKB, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dpk.p, pk, nkeys * P::PKB, hipMemcpyHostToDevice));
   if (int rc = fill_coins(dc.p, coins, n * 32)) return rc;
-  if (int rc = enc_dev<P, N90>(n, dct.p, dss.p, dpk.p, dc.p, nullptr)) return rc;
+  if (int rc = enc_dev<P, N90>(n, dct.p, dss.p, dpk.p, shared ? 0 : P::PKB, dc.p, nullptr)) return rc;
   HIP_TRY(hipMemcpy(ct, dct.p, n * P::CTB, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
   return 0;
 }
 
 template <class P, bool N90>
-int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
+int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, bool shared) {
   DevBuf dsk, dct, dss;
-  if (int rc = dsk.alloc(n * P::SKB)) return rc;
+  const size_t nkeys = shared ? 1 : n;
+  if (int rc = dsk.alloc(nkeys * P::SKB)) return rc;
   if (int rc = dct.alloc(n * P::CTB)) return rc;
   if (int rc = dss.alloc(n * 32)) return rc;
-  HIP_TRY(hipMemcpy(dsk.p, sk, n * P::SKB, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dsk.p, sk, nkeys * P::SKB, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dct.p, ct, n * P::CTB, hipMemcpyHostToDevice));
-  if (int rc = dec_dev<P, N90>(n, dss.p, dct.p, dsk.p, nullptr)) return rc;
+  if (int rc = dec_dev<P, N90>(n, dss.p, dct.p, dsk.p, shared ? 0 : P::SKB, nullptr)) return rc;
   HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -365,13 +411,26 @@ int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss,
   if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, enc_dev, n, ct, ss, pk, coins, st);
+  DISPATCH(k, nineties, enc_each_dev, n, ct, ss, pk, coins, st);
+}
+int kyber_batch_enc_shared_pk_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
+                                  void* stream) {
+  if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, enc_shared_dev, n, ct, ss, pk, coins, st);
 }
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DISPATCH(k, nineties, dec_dev, n, ss, ct, sk, st);
+  DISPATCH(k, nineties, dec_each_dev, n, ss, ct, sk, st);
+}
+int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
+  if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, dec_shared_dev, n, ss, ct, sk, st);
 }
 
 int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
@@ -382,12 +441,22 @@ int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk,
 int kyber_batch_enc(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
   if (!ct || !ss || !pk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
-  DISPATCH(k, nineties, enc_host, n, ct, ss, pk, coins);
+  DISPATCH(k, nineties, enc_host, n, ct, ss, pk, coins, false);
+}
+int kyber_batch_enc_shared_pk(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins) {
+  if (!ct || !ss || !pk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  DISPATCH(k, nineties, enc_host, n, ct, ss, pk, coins, true);
 }
 int kyber_batch_dec(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
-  DISPATCH(k, nineties, dec_host, n, ss, ct, sk);
+  DISPATCH(k, nineties, dec_host, n, ss, ct, sk, false);
+}
+int kyber_batch_dec_shared_sk(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {
+  if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
+  DISPATCH(k, nineties, dec_host, n, ss, ct, sk, true);
 }
 
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, const uint8_t* seeds, int transposed, void* stream) {

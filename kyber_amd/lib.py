@@ -60,6 +60,10 @@ def library():
         "kyber_batch_keypair_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_enc_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
+        "kyber_batch_enc_shared_pk": [ci, ci, sz, u8p, u8p, u8p, u8p],
+        "kyber_batch_dec_shared_sk": [ci, ci, sz, u8p, u8p, u8p],
+        "kyber_batch_enc_shared_pk_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
+        "kyber_batch_dec_shared_sk_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
         "kyber_batch_poly_ntt_dev": [sz, i16p, vp],
         "kyber_batch_poly_invntt_dev": [sz, i16p, vp],
@@ -164,7 +168,52 @@ class KyberHip:
         _check(self.lib.kyber_batch_dec(self.k, self.nineties, n, _ptr(ss), _ptr(ct), _ptr(sk)), "kyber_batch_dec")
         return ss
 
+    # ---- one key, many operations (host arrays) ----
+    def enc_shared_pk(self, pk, coins=None, n=None):
+        """n encapsulations to the ONE public key pk; == enc(np.tile(pk, (n, 1)), coins)."""
+        pk = _np_u8(np.asarray(pk).reshape(-1), (self.pk_bytes,), "pk")
+        if coins is not None:
+            coins = np.ascontiguousarray(coins, dtype=np.uint8).reshape(-1, 32)
+            n = coins.shape[0]
+        elif n is None:
+            raise ValueError("give coins or n")
+        ct = np.empty((n, self.ct_bytes), np.uint8)
+        ss = np.empty((n, 32), np.uint8)
+        _check(self.lib.kyber_batch_enc_shared_pk(self.k, self.nineties, n, _ptr(ct), _ptr(ss), _ptr(pk),
+                                                  _ptr(coins) if coins is not None else None), "kyber_batch_enc_shared_pk")
+        return ct, ss
+
+    def dec_shared_sk(self, ct, sk):
+        """Decapsulate every ciphertext with the ONE secret key sk."""
+        ct = np.ascontiguousarray(ct, dtype=np.uint8).reshape(-1, self.ct_bytes)
+        n = ct.shape[0]
+        sk = _np_u8(np.asarray(sk).reshape(-1), (self.sk_bytes,), "sk")
+        ss = np.empty((n, 32), np.uint8)
+        _check(self.lib.kyber_batch_dec_shared_sk(self.k, self.nineties, n, _ptr(ss), _ptr(ct), _ptr(sk)),
+               "kyber_batch_dec_shared_sk")
+        return ss
+
     # ---- device tensors (torch, uint8, CUDA) ----
+    def enc_shared_pk_dev(self, pk, coins, ct=None, ss=None):
+        import torch
+        n = coins.numel() // 32
+        ct = torch.empty((n, self.ct_bytes), dtype=torch.uint8, device=pk.device) if ct is None else ct
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=pk.device) if ss is None else ss
+        _check(self.lib.kyber_batch_enc_shared_pk_dev(self.k, self.nineties, n, _tptr(ct, n * self.ct_bytes, "ct"),
+                                                      _tptr(ss, n * 32, "ss"), _tptr(pk, self.pk_bytes, "pk"),
+                                                      _tptr(coins, n * 32, "coins"), _torch_stream()),
+               "kyber_batch_enc_shared_pk_dev")
+        return ct, ss
+
+    def dec_shared_sk_dev(self, ct, sk, ss=None):
+        import torch
+        n = ct.numel() // self.ct_bytes
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device) if ss is None else ss
+        _check(self.lib.kyber_batch_dec_shared_sk_dev(self.k, self.nineties, n, _tptr(ss, n * 32, "ss"),
+                                                      _tptr(ct, n * self.ct_bytes, "ct"), _tptr(sk, self.sk_bytes, "sk"),
+                                                      _torch_stream()), "kyber_batch_dec_shared_sk_dev")
+        return ss
+
     def keypair_dev(self, coins, pk=None, sk=None):
         import torch
         n = coins.numel() // 64
