@@ -88,6 +88,46 @@ int kyber_batch_enc_shared_pk_dev(int k, int nineties, size_t n, uint8_t *ct, ui
                                   void *stream);
 int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
 
+/* ---- key exchange: ref/kex.c:6-54, ref/kex.h:7-29, batched ----
+ * Each call is n independent runs of the reference function of the same name.
+ * Message layouts per instance are the reference's (ref/kex.h:7-12):
+ *   UAKE/AKE send A = pk || ct           (PUBLICKEYBYTES + CIPHERTEXTBYTES)
+ *   UAKE send B     = ct                 (CIPHERTEXTBYTES)
+ *   AKE  send B     = ct || ct'          (2 x CIPHERTEXTBYTES)
+ *   tk, key         = 32 bytes           (KEX_SSBYTES)
+ * all dense, instance i at base + i*size.  coins are the randombytes draws of
+ * the KEM calls inside, in call order: initA d||z||m0 (96 B per instance),
+ * uake_sharedB m0 (32), ake_sharedB m0||m0' (64); NULL = draw from randombytes
+ * (host-pointer forms only).  flags: KYBER_KEX_SHARED_B = B's static key (pkb
+ * in initA, skb in sharedB) is ONE key used for every instance, not n keys.
+ * Return 0 or a negative KYBER_HIP_* code (the reference returns void). */
+#define KYBER_KEX_SHARED_B 1
+int kyber_batch_kex_uake_initA(int k, int nineties, size_t n, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                               const uint8_t *coins, int flags);
+int kyber_batch_kex_uake_sharedB(int k, int nineties, size_t n, uint8_t *send, uint8_t *key, const uint8_t *recv,
+                                 const uint8_t *skb, const uint8_t *coins, int flags);
+int kyber_batch_kex_uake_sharedA(int k, int nineties, size_t n, uint8_t *key, const uint8_t *recv, const uint8_t *tk,
+                                 const uint8_t *sk);
+int kyber_batch_kex_ake_initA(int k, int nineties, size_t n, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                              const uint8_t *coins, int flags);
+int kyber_batch_kex_ake_sharedB(int k, int nineties, size_t n, uint8_t *send, uint8_t *key, const uint8_t *recv,
+                                const uint8_t *skb, const uint8_t *pka, const uint8_t *coins, int flags);
+int kyber_batch_kex_ake_sharedA(int k, int nineties, size_t n, uint8_t *key, const uint8_t *recv, const uint8_t *tk,
+                                const uint8_t *sk, const uint8_t *ska);
+/* device pointers, work queued on `stream` (temporaries are stream-ordered allocations) */
+int kyber_batch_kex_uake_initA_dev(int k, int nineties, size_t n, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                                   const uint8_t *coins, int flags, void *stream);
+int kyber_batch_kex_uake_sharedB_dev(int k, int nineties, size_t n, uint8_t *send, uint8_t *key, const uint8_t *recv,
+                                     const uint8_t *skb, const uint8_t *coins, int flags, void *stream);
+int kyber_batch_kex_uake_sharedA_dev(int k, int nineties, size_t n, uint8_t *key, const uint8_t *recv, const uint8_t *tk,
+                                     const uint8_t *sk, void *stream);
+int kyber_batch_kex_ake_initA_dev(int k, int nineties, size_t n, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                                  const uint8_t *coins, int flags, void *stream);
+int kyber_batch_kex_ake_sharedB_dev(int k, int nineties, size_t n, uint8_t *send, uint8_t *key, const uint8_t *recv,
+                                    const uint8_t *skb, const uint8_t *pka, const uint8_t *coins, int flags, void *stream);
+int kyber_batch_kex_ake_sharedA_dev(int k, int nineties, size_t n, uint8_t *key, const uint8_t *recv, const uint8_t *tk,
+                                    const uint8_t *sk, const uint8_t *ska, void *stream);
+
 /* per-set spellings, e.g. kyber768_batch_enc(n, ct, ss, pk, coins) */
 #define KYBER_HIP_DECLARE_SET(NAME)                                                                         \
   int NAME##_batch_keypair(size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins);                       \

@@ -116,6 +116,39 @@ __global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict
   st32Bv(ss + (size_t)i * 32, out);
 }
 
+// Key-exchange KDF over NP (2 or 3) 32-byte secrets held in separate dense
+// arrays: out = kdf(p0 || p1 [|| p2]).  ref/kex.c:17,26,42,52 with
+// ref/symmetric.h:32,56 (SHAKE256 / SHA-256).
+template <int NP, bool N90>
+__global__ void __launch_bounds__(256) k_kdf_parts(int n, const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
+                                                   const uint8_t* __restrict__ p2, uint8_t* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p a[4], b[4], c[4], r[4];
+  ld32B(p0 + (size_t)i * 32, a);
+  ld32B(p1 + (size_t)i * 32, b);
+  if constexpr (NP == 3) ld32B(p2 + (size_t)i * 32, c);
+  if constexpr (N90) {
+    if constexpr (NP == 3) sha256_96(a, b, c, r);
+    else sha256_64(a, b, r);
+  } else {
+    u64p A[25];
+    keccak_zero(A);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      A[w] = a[w];
+      A[4 + w] = b[w];
+      if constexpr (NP == 3) A[8 + w] = c[w];
+    }
+    A[4 * NP].lo = 0x1F;
+    A[16].hi = 0x80000000u;
+    keccak_f1600(A);
+#pragma unroll
+    for (int w = 0; w < 4; w++) r[w] = A[w];
+  }
+  st32Bv(out + (size_t)i * 32, r);
+}
+
 // PRF: AES-256-CTR(key = seed, nonce = {nonce,0,...}) from counter 0.
 // ref/symmetric-aes.c:15-20 -> ref/aes256ctr.c:557-563.  Jobs are nonce-major.
 template <class P>

@@ -289,6 +289,109 @@ int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed,
   return 0;
 }
 
+// ---- key exchange (ref/kex.c:6-54) as batched compositions ----------------------
+// The protocol messages interleave a key and a ciphertext per instance
+// (ref/kex.h:7-12) while the KEM pipelines work on dense arrays, so messages
+// are split/joined with strided device copies into stream-ordered temporaries.
+struct AsyncBuf {
+  uint8_t* p = nullptr;
+  hipStream_t st = nullptr;
+  ~AsyncBuf() {
+    if (p) (void)hipFreeAsync(p, st);
+  }
+  int alloc(size_t bytes, hipStream_t s) {
+    st = s;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&p), bytes ? bytes : 16, s));
+    return 0;
+  }
+};
+
+// dst[i][0..w) = src[i][0..w) for n rows with the given row pitches
+inline int copy_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t w, size_t n, hipStream_t st) {
+  HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, w, n, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+template <int NP, bool N90>
+int kdf_parts(size_t n, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, uint8_t* out, hipStream_t st) {
+  RUN("k_kdf_parts", st, k_kdf_parts<NP, N90><<<blocks(n, 256), 256, 0, st>>>((int)n, p0, p1, p2, out));
+  return 0;
+}
+
+#define KX(call)              \
+  do {                        \
+    if (int rc_ = (call)) return rc_; \
+  } while (0)
+
+// kex_uake_initA == kex_ake_initA (ref/kex.c:6-10, :30-34): ephemeral keypair, encapsulate to B's static key
+template <class P, bool N90>
+int kex_initA_dev(size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb, const uint8_t* coins, int shared_b,
+                  hipStream_t st) {
+  AsyncBuf pk, ct, kc, ec;
+  KX(pk.alloc(n * P::PKB, st)); KX(ct.alloc(n * P::CTB, st)); KX(kc.alloc(n * 64, st)); KX(ec.alloc(n * 32, st));
+  KX(copy_rows(kc.p, 64, coins, 96, 64, n, st));
+  KX(copy_rows(ec.p, 32, coins + 64, 96, 32, n, st));
+  KX((keypair_dev<P, N90>(n, pk.p, sk, kc.p, st)));
+  KX((enc_dev<P, N90>(n, ct.p, tk, pkb, shared_b ? 0 : P::PKB, ec.p, st)));
+  KX(copy_rows(send, P::PKB + P::CTB, pk.p, P::PKB, P::PKB, n, st));
+  KX(copy_rows(send + P::PKB, P::PKB + P::CTB, ct.p, P::CTB, P::CTB, n, st));
+  return 0;
+}
+
+// ref/kex.c:12-18
+template <class P, bool N90>
+int kex_uake_sharedB_dev(size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv, const uint8_t* skb, const uint8_t* coins,
+                         int shared_b, hipStream_t st) {
+  AsyncBuf pk, ct, s0, s1;
+  KX(pk.alloc(n * P::PKB, st)); KX(ct.alloc(n * P::CTB, st)); KX(s0.alloc(n * 32, st)); KX(s1.alloc(n * 32, st));
+  KX(copy_rows(pk.p, P::PKB, recv, P::PKB + P::CTB, P::PKB, n, st));
+  KX(copy_rows(ct.p, P::CTB, recv + P::PKB, P::PKB + P::CTB, P::CTB, n, st));
+  KX((enc_dev<P, N90>(n, send, s0.p, pk.p, P::PKB, coins, st)));
+  KX((dec_dev<P, N90>(n, s1.p, ct.p, skb, shared_b ? 0 : P::SKB, st)));
+  return kdf_parts<2, N90>(n, s0.p, s1.p, nullptr, key, st);
+}
+
+// ref/kex.c:20-27
+template <class P, bool N90>
+int kex_uake_sharedA_dev(size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk, const uint8_t* sk, hipStream_t st) {
+  AsyncBuf s0;
+  KX(s0.alloc(n * 32, st));
+  KX((dec_dev<P, N90>(n, s0.p, recv, sk, P::SKB, st)));
+  return kdf_parts<2, N90>(n, s0.p, tk, nullptr, key, st);
+}
+
+// ref/kex.c:36-43
+template <class P, bool N90>
+int kex_ake_sharedB_dev(size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv, const uint8_t* skb, const uint8_t* pka,
+                        const uint8_t* coins, int shared_b, hipStream_t st) {
+  AsyncBuf pk, ct, ct0, ct1, s0, s1, s2, c0, c1;
+  KX(pk.alloc(n * P::PKB, st)); KX(ct.alloc(n * P::CTB, st)); KX(ct0.alloc(n * P::CTB, st)); KX(ct1.alloc(n * P::CTB, st));
+  KX(s0.alloc(n * 32, st)); KX(s1.alloc(n * 32, st)); KX(s2.alloc(n * 32, st)); KX(c0.alloc(n * 32, st)); KX(c1.alloc(n * 32, st));
+  KX(copy_rows(pk.p, P::PKB, recv, P::PKB + P::CTB, P::PKB, n, st));
+  KX(copy_rows(ct.p, P::CTB, recv + P::PKB, P::PKB + P::CTB, P::CTB, n, st));
+  KX(copy_rows(c0.p, 32, coins, 64, 32, n, st));
+  KX(copy_rows(c1.p, 32, coins + 32, 64, 32, n, st));
+  KX((enc_dev<P, N90>(n, ct0.p, s0.p, pk.p, P::PKB, c0.p, st)));
+  KX((enc_dev<P, N90>(n, ct1.p, s1.p, pka, P::PKB, c1.p, st)));
+  KX((dec_dev<P, N90>(n, s2.p, ct.p, skb, shared_b ? 0 : P::SKB, st)));
+  KX(copy_rows(send, 2 * P::CTB, ct0.p, P::CTB, P::CTB, n, st));
+  KX(copy_rows(send + P::CTB, 2 * P::CTB, ct1.p, P::CTB, P::CTB, n, st));
+  return kdf_parts<3, N90>(n, s0.p, s1.p, s2.p, key, st);
+}
+
+// ref/kex.c:45-54
+template <class P, bool N90>
+int kex_ake_sharedA_dev(size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk, const uint8_t* sk, const uint8_t* ska,
+                        hipStream_t st) {
+  AsyncBuf ct0, ct1, s0, s1;
+  KX(ct0.alloc(n * P::CTB, st)); KX(ct1.alloc(n * P::CTB, st)); KX(s0.alloc(n * 32, st)); KX(s1.alloc(n * 32, st));
+  KX(copy_rows(ct0.p, P::CTB, recv, 2 * P::CTB, P::CTB, n, st));
+  KX(copy_rows(ct1.p, P::CTB, recv + P::CTB, 2 * P::CTB, P::CTB, n, st));
+  KX((dec_dev<P, N90>(n, s0.p, ct0.p, sk, P::SKB, st)));
+  KX((dec_dev<P, N90>(n, s1.p, ct1.p, ska, P::SKB, st)));
+  return kdf_parts<3, N90>(n, s0.p, s1.p, tk, key, st);
+}
+
 // ---- host-pointer wrappers ---------------------------------------------------
 struct DevBuf {
   uint8_t* p = nullptr;
@@ -376,6 +479,84 @@ int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, bool s
   return 0;
 }
 
+// Host-pointer form of a device-pointer routine: stage every argument in device
+// memory, run `f` on the null stream, copy the outputs back.
+struct HostArg {
+  const void* in;  // copied to the device before the call (may be null)
+  void* out;       // copied back after the call (may be null)
+  size_t bytes;
+};
+template <class F>
+int with_device(std::initializer_list<HostArg> args, F&& f) {
+  std::vector<DevBuf> bufs(args.size());
+  std::vector<uint8_t*> ptr(args.size());
+  size_t i = 0;
+  for (const HostArg& a : args) {
+    if (int rc = bufs[i].alloc(a.bytes)) return rc;
+    if (a.in) HIP_TRY(hipMemcpy(bufs[i].p, a.in, a.bytes, hipMemcpyHostToDevice));
+    ptr[i] = bufs[i].p;
+    i++;
+  }
+  if (int rc = f(ptr.data())) return rc;
+  i = 0;
+  for (const HostArg& a : args) {
+    if (a.out) HIP_TRY(hipMemcpy(a.out, bufs[i].p, a.bytes, hipMemcpyDeviceToHost));
+    i++;
+  }
+  return 0;
+}
+
+// coins == NULL: draw them from randombytes (zeroised afterwards)
+struct Coins {
+  std::vector<uint8_t> own;
+  const uint8_t* p;
+  Coins(const uint8_t* given, size_t bytes) : p(given) {
+    if (!given) {
+      own.resize(bytes ? bytes : 1);
+      randombytes(own.data(), bytes);
+      p = own.data();
+    }
+  }
+  ~Coins() {
+    if (!own.empty()) memset(own.data(), 0, own.size());
+  }
+};
+
+template <class P, bool N90>
+int kex_initA_host(size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb, const uint8_t* coins, int shared_b) {
+  Coins c(coins, n * 96);
+  return with_device({{nullptr, send, n * (P::PKB + P::CTB)}, {nullptr, tk, n * 32}, {nullptr, sk, n * P::SKB},
+                      {pkb, nullptr, (shared_b ? 1 : n) * P::PKB}, {c.p, nullptr, n * 96}},
+                     [&](uint8_t** d) { return kex_initA_dev<P, N90>(n, d[0], d[1], d[2], d[3], d[4], shared_b, nullptr); });
+}
+template <class P, bool N90>
+int kex_uake_sharedB_host(size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv, const uint8_t* skb, const uint8_t* coins,
+                          int shared_b) {
+  Coins c(coins, n * 32);
+  return with_device({{nullptr, send, n * P::CTB}, {nullptr, key, n * 32}, {recv, nullptr, n * (P::PKB + P::CTB)},
+                      {skb, nullptr, (shared_b ? 1 : n) * P::SKB}, {c.p, nullptr, n * 32}},
+                     [&](uint8_t** d) { return kex_uake_sharedB_dev<P, N90>(n, d[0], d[1], d[2], d[3], d[4], shared_b, nullptr); });
+}
+template <class P, bool N90>
+int kex_uake_sharedA_host(size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk, const uint8_t* sk) {
+  return with_device({{nullptr, key, n * 32}, {recv, nullptr, n * P::CTB}, {tk, nullptr, n * 32}, {sk, nullptr, n * P::SKB}},
+                     [&](uint8_t** d) { return kex_uake_sharedA_dev<P, N90>(n, d[0], d[1], d[2], d[3], nullptr); });
+}
+template <class P, bool N90>
+int kex_ake_sharedB_host(size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv, const uint8_t* skb, const uint8_t* pka,
+                         const uint8_t* coins, int shared_b) {
+  Coins c(coins, n * 64);
+  return with_device({{nullptr, send, n * 2 * P::CTB}, {nullptr, key, n * 32}, {recv, nullptr, n * (P::PKB + P::CTB)},
+                      {skb, nullptr, (shared_b ? 1 : n) * P::SKB}, {pka, nullptr, n * P::PKB}, {c.p, nullptr, n * 64}},
+                     [&](uint8_t** d) { return kex_ake_sharedB_dev<P, N90>(n, d[0], d[1], d[2], d[3], d[4], d[5], shared_b, nullptr); });
+}
+template <class P, bool N90>
+int kex_ake_sharedA_host(size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk, const uint8_t* sk, const uint8_t* ska) {
+  return with_device({{nullptr, key, n * 32}, {recv, nullptr, n * 2 * P::CTB}, {tk, nullptr, n * 32}, {sk, nullptr, n * P::SKB},
+                      {ska, nullptr, n * P::SKB}},
+                     [&](uint8_t** d) { return kex_ake_sharedA_dev<P, N90>(n, d[0], d[1], d[2], d[3], d[4], nullptr); });
+}
+
 // dispatch on the run-time parameter set
 #define DISPATCH(K, NINETIES, FN, ...)                                   \
   do {                                                                    \
@@ -457,6 +638,83 @@ int kyber_batch_dec_shared_sk(int k, int nineties, size_t n, uint8_t* ss, const 
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
   DISPATCH(k, nineties, dec_host, n, ss, ct, sk, true);
+}
+
+// ---- key exchange ----
+#define KEX_PRECHECK(cond)                                       \
+  do {                                                           \
+    if (!(cond) || (flags & ~KYBER_KEX_SHARED_B)) return KYBER_HIP_EINVAL; \
+    if (k < 2 || k > 4) return KYBER_HIP_EINVAL;                 \
+    if (n == 0) return 0;                                        \
+  } while (0)
+
+int kyber_batch_kex_uake_initA(int k, int nineties, size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb,
+                               const uint8_t* coins, int flags) {
+  KEX_PRECHECK(send && tk && sk && pkb);
+  DISPATCH(k, nineties, kex_initA_host, n, send, tk, sk, pkb, coins, flags & KYBER_KEX_SHARED_B);
+}
+int kyber_batch_kex_ake_initA(int k, int nineties, size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb,
+                              const uint8_t* coins, int flags) {
+  return kyber_batch_kex_uake_initA(k, nineties, n, send, tk, sk, pkb, coins, flags);  // same body, ref/kex.c:30-34
+}
+int kyber_batch_kex_uake_sharedB(int k, int nineties, size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv,
+                                 const uint8_t* skb, const uint8_t* coins, int flags) {
+  KEX_PRECHECK(send && key && recv && skb);
+  DISPATCH(k, nineties, kex_uake_sharedB_host, n, send, key, recv, skb, coins, flags & KYBER_KEX_SHARED_B);
+}
+int kyber_batch_kex_uake_sharedA(int k, int nineties, size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk,
+                                 const uint8_t* sk) {
+  const int flags = 0;
+  KEX_PRECHECK(key && recv && tk && sk);
+  DISPATCH(k, nineties, kex_uake_sharedA_host, n, key, recv, tk, sk);
+}
+int kyber_batch_kex_ake_sharedB(int k, int nineties, size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv,
+                                const uint8_t* skb, const uint8_t* pka, const uint8_t* coins, int flags) {
+  KEX_PRECHECK(send && key && recv && skb && pka);
+  DISPATCH(k, nineties, kex_ake_sharedB_host, n, send, key, recv, skb, pka, coins, flags & KYBER_KEX_SHARED_B);
+}
+int kyber_batch_kex_ake_sharedA(int k, int nineties, size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk,
+                                const uint8_t* sk, const uint8_t* ska) {
+  const int flags = 0;
+  KEX_PRECHECK(key && recv && tk && sk && ska);
+  DISPATCH(k, nineties, kex_ake_sharedA_host, n, key, recv, tk, sk, ska);
+}
+
+int kyber_batch_kex_uake_initA_dev(int k, int nineties, size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb,
+                                   const uint8_t* coins, int flags, void* stream) {
+  KEX_PRECHECK(send && tk && sk && pkb && coins);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, kex_initA_dev, n, send, tk, sk, pkb, coins, flags & KYBER_KEX_SHARED_B, st);
+}
+int kyber_batch_kex_ake_initA_dev(int k, int nineties, size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb,
+                                  const uint8_t* coins, int flags, void* stream) {
+  return kyber_batch_kex_uake_initA_dev(k, nineties, n, send, tk, sk, pkb, coins, flags, stream);
+}
+int kyber_batch_kex_uake_sharedB_dev(int k, int nineties, size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv,
+                                     const uint8_t* skb, const uint8_t* coins, int flags, void* stream) {
+  KEX_PRECHECK(send && key && recv && skb && coins);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, kex_uake_sharedB_dev, n, send, key, recv, skb, coins, flags & KYBER_KEX_SHARED_B, st);
+}
+int kyber_batch_kex_uake_sharedA_dev(int k, int nineties, size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk,
+                                     const uint8_t* sk, void* stream) {
+  const int flags = 0;
+  KEX_PRECHECK(key && recv && tk && sk);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, kex_uake_sharedA_dev, n, key, recv, tk, sk, st);
+}
+int kyber_batch_kex_ake_sharedB_dev(int k, int nineties, size_t n, uint8_t* send, uint8_t* key, const uint8_t* recv,
+                                    const uint8_t* skb, const uint8_t* pka, const uint8_t* coins, int flags, void* stream) {
+  KEX_PRECHECK(send && key && recv && skb && pka && coins);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, kex_ake_sharedB_dev, n, send, key, recv, skb, pka, coins, flags & KYBER_KEX_SHARED_B, st);
+}
+int kyber_batch_kex_ake_sharedA_dev(int k, int nineties, size_t n, uint8_t* key, const uint8_t* recv, const uint8_t* tk,
+                                    const uint8_t* sk, const uint8_t* ska, void* stream) {
+  const int flags = 0;
+  KEX_PRECHECK(key && recv && tk && sk && ska);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, kex_ake_sharedA_dev, n, key, recv, tk, sk, ska, st);
 }
 
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, const uint8_t* seeds, int transposed, void* stream) {

@@ -119,6 +119,22 @@ __device__ __forceinline__ void sha256_64(const u64p (&a)[4], const u64p (&b)[4]
   sha256_digest_le(h, out);
 }
 
+// sha256 of a 96-byte string a || b || c                      (kdf over three secrets, ref/kex.c:42,52)
+__device__ __forceinline__ void sha256_96(const u64p (&a)[4], const u64p (&b)[4], const u64p (&c)[4], u64p (&out)[4]) {
+  uint32_t h[8], w[16];
+  sha256_init(h);
+  le_to_be_words(a, w);
+  le_to_be_words(b, w + 8);
+  sha256_compress(h, w);
+  le_to_be_words(c, w);
+  w[8] = 0x80000000u;
+#pragma unroll
+  for (int i = 9; i < 15; i++) w[i] = 0;
+  w[15] = 768;
+  sha256_compress(h, w);
+  sha256_digest_le(h, out);
+}
+
 // ---------------------------------------------------------------- SHA-512 (single block)
 __device__ __forceinline__ uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 

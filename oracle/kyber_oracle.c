@@ -326,8 +326,9 @@ static void hash_h(const ko_params *p, uint8_t out[32], const uint8_t *in, size_
 { if (p->nineties) ko_sha256(out, in, n); else ko_sha3_256(out, in, n); }
 static void hash_g(const ko_params *p, uint8_t out[64], const uint8_t *in, size_t n)
 { if (p->nineties) ko_sha512(out, in, n); else ko_sha3_512(out, in, n); }
-static void kdf(const ko_params *p, uint8_t out[32], const uint8_t in[64])
-{ if (p->nineties) ko_sha256(out, in, 64); else ko_shake256(out, 32, in, 64); }
+static void kdf_n(const ko_params *p, uint8_t out[32], const uint8_t *in, size_t n)
+{ if (p->nineties) ko_sha256(out, in, n); else ko_shake256(out, 32, in, n); }
+static void kdf(const ko_params *p, uint8_t out[32], const uint8_t in[64]) { kdf_n(p, out, in, 64); }
 
 /* ref/symmetric-shake.c:43-51 and ref/symmetric-aes.c:15-20 */
 static void prf(const ko_params *p, uint8_t *out, size_t outlen, const uint8_t key[32], uint8_t nonce)
@@ -697,6 +698,60 @@ void ko_kem_dec(const ko_params *p, uint8_t *ss, const uint8_t *ct, const uint8_
   uint8_t mask = (uint8_t)-(uint8_t)(diff != 0);                  /* cmov,   ref/verify.c:40-47 */
   for (int i = 0; i < 32; i++) kr[i] ^= mask & (kr[i] ^ z[i]);
   kdf(p, ss, kr);
+}
+
+/* ------------------------------------------------------------------ */
+/* key exchange, ref/kex.c:6-54 (coins replace the randombytes draws of   */
+/* the KEM calls inside, in call order)                                   */
+/* ------------------------------------------------------------------ */
+void ko_kex_uake_initA(const ko_params *p, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                       const uint8_t coins[96])
+{
+  ko_kem_keypair(p, send, sk, coins);                      /* kex.c:8 */
+  ko_kem_enc(p, send + ko_pk_bytes(p), tk, pkb, coins + 64); /* kex.c:9 */
+}
+
+void ko_kex_uake_sharedB(const ko_params *p, uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb,
+                         const uint8_t coins[32])
+{
+  uint8_t buf[64];
+  ko_kem_enc(p, send, buf, recv, coins);                   /* kex.c:15 */
+  ko_kem_dec(p, buf + 32, recv + ko_pk_bytes(p), skb);     /* kex.c:16 */
+  kdf_n(p, k, buf, 64);
+}
+
+void ko_kex_uake_sharedA(const ko_params *p, uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk)
+{
+  uint8_t buf[64];
+  ko_kem_dec(p, buf, recv, sk);                            /* kex.c:24 */
+  memcpy(buf + 32, tk, 32);
+  kdf_n(p, k, buf, 64);
+}
+
+void ko_kex_ake_initA(const ko_params *p, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb,
+                      const uint8_t coins[96])
+{
+  ko_kex_uake_initA(p, send, tk, sk, pkb, coins);          /* kex.c:30-34, same body */
+}
+
+void ko_kex_ake_sharedB(const ko_params *p, uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb,
+                        const uint8_t *pka, const uint8_t coins[64])
+{
+  uint8_t buf[96];
+  ko_kem_enc(p, send, buf, recv, coins);                             /* kex.c:39 */
+  ko_kem_enc(p, send + ko_ct_bytes(p), buf + 32, pka, coins + 32);   /* kex.c:40 */
+  ko_kem_dec(p, buf + 64, recv + ko_pk_bytes(p), skb);               /* kex.c:41 */
+  kdf_n(p, k, buf, 96);
+}
+
+void ko_kex_ake_sharedA(const ko_params *p, uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk,
+                        const uint8_t *ska)
+{
+  uint8_t buf[96];
+  ko_kem_dec(p, buf, recv, sk);                            /* kex.c:49 */
+  ko_kem_dec(p, buf + 32, recv + ko_ct_bytes(p), ska);     /* kex.c:50 */
+  memcpy(buf + 64, tk, 32);
+  kdf_n(p, k, buf, 96);
 }
 
 void ko_batch_keypair(const ko_params *p, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins)

@@ -51,6 +51,16 @@ void ko_kem_dec(const ko_params *p, uint8_t *ss, const uint8_t *ct, const uint8_
 
 /* batched helpers (plain loops) used as the CPU side of parity tests and as
  * the "port" CPU baseline; instance i lives at base + i*<bytes>. */
+/* key exchange (ref/kex.c:6-54, ref/kex.h:7-29); one instance per call.
+ * coins: initA d||z||m0 (96), uake_sharedB m0 (32), ake_sharedB m0||m0' (64). */
+void ko_kex_uake_initA(const ko_params *p, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb, const uint8_t coins[96]);
+void ko_kex_uake_sharedB(const ko_params *p, uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb, const uint8_t coins[32]);
+void ko_kex_uake_sharedA(const ko_params *p, uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk);
+void ko_kex_ake_initA(const ko_params *p, uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb, const uint8_t coins[96]);
+void ko_kex_ake_sharedB(const ko_params *p, uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb, const uint8_t *pka,
+                        const uint8_t coins[64]);
+void ko_kex_ake_sharedA(const ko_params *p, uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk, const uint8_t *ska);
+
 void ko_batch_keypair(const ko_params *p, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins);
 void ko_batch_enc(const ko_params *p, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins);
 void ko_batch_dec(const ko_params *p, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);

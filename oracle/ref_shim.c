@@ -14,6 +14,7 @@
 #include <string.h>
 #include "kem.h"          /* the reference's header, found through -I */
 #include "randombytes.h"
+#include "kex.h"
 
 static __thread const uint8_t *coin_cursor;
 
@@ -52,3 +53,17 @@ int refshim_batch_dec(size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *s
     crypto_kem_dec(ss + i * CRYPTO_BYTES, ct + i * CRYPTO_CIPHERTEXTBYTES, sk + i * CRYPTO_SECRETKEYBYTES);
   return 0;
 }
+
+/* the reference's key exchange (ref/kex.c), one instance, coins in call order */
+void refshim_kex_uake_initA(uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb, const uint8_t *coins)
+{ coin_cursor = coins; kex_uake_initA(send, tk, sk, pkb); }
+void refshim_kex_uake_sharedB(uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb, const uint8_t *coins)
+{ coin_cursor = coins; kex_uake_sharedB(send, k, recv, skb); }
+void refshim_kex_uake_sharedA(uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk)
+{ kex_uake_sharedA(k, recv, tk, sk); }
+void refshim_kex_ake_initA(uint8_t *send, uint8_t *tk, uint8_t *sk, const uint8_t *pkb, const uint8_t *coins)
+{ coin_cursor = coins; kex_ake_initA(send, tk, sk, pkb); }
+void refshim_kex_ake_sharedB(uint8_t *send, uint8_t *k, const uint8_t *recv, const uint8_t *skb, const uint8_t *pka, const uint8_t *coins)
+{ coin_cursor = coins; kex_ake_sharedB(send, k, recv, skb, pka); }
+void refshim_kex_ake_sharedA(uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk, const uint8_t *ska)
+{ kex_ake_sharedA(k, recv, tk, sk, ska); }

@@ -26,7 +26,59 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _Kex:
+    """ref/kex.c's six functions over dense per-instance arrays (instance i at
+    row i), driven one instance at a time through `call(name, *row_pointers)`."""
+
+    def __init__(self, call, pkb, skb, ctb):
+        self.call, self.pkb, self.skb, self.ctb = call, pkb, skb, ctb
+
+    @staticmethod
+    def _rows(a, width):
+        return np.ascontiguousarray(a, np.uint8).reshape(-1, width)
+
+    def _run(self, name, outs, ins):
+        n = ins[0].shape[0]
+        outs = [np.zeros((n, w), np.uint8) for w in outs]
+        for i in range(n):
+            self.call(name, *[_p(o[i]) for o in outs], *[_p(a[i]) for a in ins])
+        return outs
+
+    def uake_initA(self, pkb, coins):
+        return self._run("uake_initA", [self.pkb + self.ctb, 32, self.skb], [self._rows(pkb, self.pkb), self._rows(coins, 96)])
+
+    def ake_initA(self, pkb, coins):
+        return self._run("ake_initA", [self.pkb + self.ctb, 32, self.skb], [self._rows(pkb, self.pkb), self._rows(coins, 96)])
+
+    def uake_sharedB(self, recv, skb, coins):
+        return self._run("uake_sharedB", [self.ctb, 32],
+                         [self._rows(recv, self.pkb + self.ctb), self._rows(skb, self.skb), self._rows(coins, 32)])
+
+    def uake_sharedA(self, recv, tk, sk):
+        return self._run("uake_sharedA", [32], [self._rows(recv, self.ctb), self._rows(tk, 32), self._rows(sk, self.skb)])[0]
+
+    def ake_sharedB(self, recv, skb, pka, coins):
+        return self._run("ake_sharedB", [2 * self.ctb, 32],
+                         [self._rows(recv, self.pkb + self.ctb), self._rows(skb, self.skb), self._rows(pka, self.pkb),
+                          self._rows(coins, 64)])
+
+    def ake_sharedA(self, recv, tk, sk, ska):
+        return self._run("ake_sharedA", [32], [self._rows(recv, 2 * self.ctb), self._rows(tk, 32), self._rows(sk, self.skb),
+                                               self._rows(ska, self.skb)])[0]
+
+
 class Oracle:
+    def kex(self, k, nineties=0):
+        """-> _Kex over the oracle's ko_kex_* (ref/kex.c restated)."""
+        p = self.params(k, nineties)
+        pkb, skb, ctb = self.sizes(k)
+
+        def call(name, *ptrs):
+            fn = getattr(self.lib, "ko_kex_" + name)
+            fn.restype = None
+            fn(ctypes.byref(p), *ptrs)
+        return _Kex(call, pkb, skb, ctb)
+
     def __init__(self, lib):
         self.lib = lib
         vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
@@ -159,6 +211,14 @@ class RefLib:
         self.lib.refshim_batch_dec.argtypes = [sz, vp, vp, vp]
         self.pkb, self.skb, self.ctb = (self.lib.refshim_pk_bytes(), self.lib.refshim_sk_bytes(),
                                         self.lib.refshim_ct_bytes())
+
+    def kex(self):
+        """-> _Kex over the reference's own kex.c (through the shim's coin cursor)."""
+        def call(name, *ptrs):
+            fn = getattr(self.lib, "refshim_kex_" + name)
+            fn.restype = None
+            fn(*ptrs)
+        return _Kex(call, self.pkb, self.skb, self.ctb)
 
     def keypair(self, coins):
         coins = np.ascontiguousarray(coins, np.uint8).reshape(-1, 64)
