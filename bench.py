@@ -35,6 +35,7 @@ WORKLOADS = {  # name: (k, nineties, compulsory enc+dec bytes, Keccak-f per enc+
 SEED0 = 0x4B59424552  # "KYBER", SURVEY.md §8(d)
 
 # algorithmic constants (restated in DESIGN.md)
+DEFAULT_CHUNK = 1 << 19            # kyber_hip.hip: instances per internal pass = units per launch
 KECCAK_LANE_OPS = 6240           # 32-bit lane-ops per Keccak-f[1600] as written in the reference
 VALU_PEAK_TLOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, full-rate 32-bit int ops
 HBM_PEAK_GBS = 8000.0
@@ -52,7 +53,7 @@ def pmc_traffic(kernel, k, chunk):
     Counters cannot be read from inside this process, so the figure is the
     recorded one for the same launch size, or None."""
     import glob
-    if chunk != 1 << 17:
+    if chunk != DEFAULT_CHUNK:
         return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -175,6 +176,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="KEM instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="instances per internal pass (0 = library default)")
     ap.add_argument("--shared-key", action="store_true",
                     help="side measurement: every instance uses ONE key pair (kyber_batch_enc_shared_pk / dec_shared_sk)")
     ap.add_argument("--workload", default="kyber768", choices=sorted(WORKLOADS) + ["ntt"],
@@ -208,6 +210,8 @@ def main():
 
     dev = torch.device("cuda", local)
     kem = kyber_amd.KyberHip(K, N90)
+    if args.chunk:
+        kl.set_chunk(args.chunk)
     n = args.batch
     gen = torch.Generator(device=dev)
     gen.manual_seed(SEED0 + rank)
@@ -273,7 +277,7 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
-        chunk = min(n, 1 << 17)
+        chunk = min(n, args.chunk or DEFAULT_CHUNK)
         if dom in ("k_sample_matrix", "k90_sample_matrix"):
             entries = chunk * K * K
             ops = entries * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS

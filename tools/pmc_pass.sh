@@ -4,4 +4,4 @@
 set -e
 tag=$1; shift
 export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 1 --batch 131072 --no-cpu-baseline > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err
+timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 1 --warmup 1 --batch 524288 --no-cpu-baseline > gpurun_out/pmc_$tag.json 2> gpurun_out/pmc_$tag.err

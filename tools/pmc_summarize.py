@@ -27,7 +27,7 @@ if as_json:
         w = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
         out[k] = {"launches": cnt[k]["FETCH_SIZE"], "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
                   "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    print(json.dumps({"note": "bench.py --steps 1 --warmup 1 --batch 131072 (one chunk per launch); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+    print(json.dumps({"note": "bench.py --steps 1 --warmup 1 --batch 524288 (one chunk of 2^19 instances per launch); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
                       "kernels": out}, indent=1))
     sys.exit(0)
 for k in sorted(agg):
