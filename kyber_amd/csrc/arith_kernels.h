@@ -1,0 +1,350 @@
+// arith_kernels.h -- the poly-layout kernels: 32 work-items per polynomial, 8 KEM
+// instances per 256-thread workgroup, polynomials in LDS (see kem_kernels.h for
+// the overall pipeline).  Compiled in their own translation unit
+// (kyber_arith.hip) with the SLP vectorizer off: it packs the fp32 butterflies
+// into v_pk_fma_f32 / v_pk_add_f32, which issue at half rate on gfx950 and need
+// s_nop padding, and measured 5 % slower than the scalar fp32 stream.
+//
+// Reference call trees restated: ref/indcpa.c:205-329, ref/poly.c, ref/polyvec.c, ref/ntt.c.
+#pragma once
+#include "params.h"
+#include "poly.h"
+#include "fpoly.h"
+
+namespace ky {
+
+// ------------------------------------------------------------------ poly-layout helpers
+struct Grp {
+  int g, t;  // group in workgroup (0..7), work-item in group (0..31)
+};
+__device__ __forceinline__ Grp grp() { return Grp{(int)threadIdx.x >> 5, (int)threadIdx.x & 31}; }
+
+__device__ __forceinline__ void ld_coef8(const int16_t* p, int t, int (&c)[8]) {
+  unpack8(*reinterpret_cast<const uint4*>(p + 8 * t), c);
+}
+
+// The three arithmetic kernels below run on the fp32 engine of fpoly.h (plain
+// residues, no Montgomery domain).  What they write -- pk, sk, ct, m' -- are
+// canonical byte strings, identical to the reference's.
+
+__device__ __forceinline__ void ld_coef8f(const int16_t* p, int t, float (&f)[8]) {
+  int c[8];
+  ld_coef8(p, t, c);
+  i2f8(c, f);
+}
+__device__ __forceinline__ void ld_bytes12f(const uint8_t* p, int t, float (&f)[8]) {
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(p) + 3 * t;
+  int c[8];
+  frombytes12(s[0], s[1], s[2], c);
+  i2f8(c, f);
+}
+__device__ __forceinline__ void st_bytes12(uint8_t* p, int t, const int (&c)[8]) {
+  uint32_t w0, w1, w2;
+  tobytes12(c, w0, w1, w2);
+  uint32_t* o = reinterpret_cast<uint32_t*>(p) + 3 * t;
+  o[0] = w0; o[1] = w1; o[2] = w2;
+}
+
+// ------------------------------------------------------------------ keypair arithmetic
+// ref/indcpa.c:220-238: s,e <- CBD(PRF); s^,e^ = NTT; t^ = A s^ + e^;
+// pk = tobytes(t^) || rho ; sk = tobytes(s^) (|| pk copy, ref/kem.c:28-29)
+template <class P>
+__global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
+                                                  const uint8_t* __restrict__ prf, uint8_t* __restrict__ pk,
+                                                  uint8_t* __restrict__ sk) {
+  constexpr int K = P::K;
+  __shared__ __attribute__((aligned(16))) int16_t se[G_INST][2 * K][256];  // s^ then e^
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ float ztab[128];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
+
+  for (int q = w.g; q < G_INST * 2 * K; q += 8) {
+    const int li = q / (2 * K), v = q % (2 * K);
+    const int gi = min(inst0 + li, n - 1);
+    int c[8];
+    float f[8];
+    cbd_contig<P::ETA1>(prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE, w.t, c);
+    i2f8(c, f);
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    f_put_i16(se[li][v], w.t, f);
+    if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
+      f2canon8(f, c);
+      st_bytes12(sk + (size_t)gi * P::SKB + 384 * v, w.t, c);
+    }
+  }
+  __syncthreads();
+  for (int q = w.g; q < G_INST * K; q += 8) {
+    const int li = q / K, i = q % K;
+    const int gi = min(inst0 + li, n - 1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      ld_coef8f(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
+      f_get_i16(se[li][j], w.t, b);
+      f_basemul_acc(acc, a, b, ztab, w.t);
+    }
+    f_get_i16(se[li][K + i], w.t, b);
+    int c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + b[k]));  // + e^   ref/indcpa.c:234-235
+    if (inst0 + li < n) {
+      st_bytes12(pk + (size_t)gi * P::PKB + 384 * i, w.t, c);
+      st_bytes12(sk + (size_t)gi * P::SKB + P::PVB + 384 * i, w.t, c);
+    }
+  }
+  // rho -> pk tail and its copy inside sk
+  if (threadIdx.x < G_INST * 8) {
+    const int li = threadIdx.x >> 3, wd = threadIdx.x & 7;
+    if (inst0 + li < n) {
+      const size_t gi = inst0 + li;
+      uint32_t r = reinterpret_cast<const uint32_t*>(small + gi * SMALL)[wd];
+      reinterpret_cast<uint32_t*>(pk + gi * P::PKB + P::PVB)[wd] = r;
+      reinterpret_cast<uint32_t*>(sk + gi * P::SKB + 2 * P::PVB)[wd] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ encryption arithmetic
+// ref/indcpa.c:268-295.  CMP = false: write the ciphertext.  CMP = true
+// (decapsulation's re-encryption, ref/kem.c:114-116): compare with the given
+// ciphertext instead and raise the instance's fail flag on any difference.
+template <class P, bool CMP>
+__global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
+                                                   uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
+                                                   size_t mat_stride,  // int16 per instance; 0 = one matrix for all
+                                                   const uint8_t* __restrict__ prf, uint8_t* __restrict__ ct) {
+  constexpr int K = P::K, NJ = 2 * K + 1;
+  __shared__ __attribute__((aligned(16))) int16_t sp[G_INST][K][256];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
+  __shared__ uint32_t bad[G_INST];
+  __shared__ float ztab[128];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
+  if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
+
+  // Global operands are fetched one loop iteration ahead of their use: each
+  // iteration's dependent chain (LDS transposes inside the transforms) is long
+  // enough to hide an HBM round trip that would otherwise be paid in full at
+  // 3-4 waves per SIMD.
+
+  // r^ = NTT(CBD_eta1(PRF(r, j)))
+  {
+    auto fetch = [&](int q, uint32_t (&r)[3]) {
+      const int li = q / K, j = q % K;
+      const int gi = min(inst0 + li, n - 1);
+      const uint8_t* b = prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE;
+      if constexpr (P::ETA1 == 2) {
+        r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+      } else {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
+        r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+      }
+    };
+    uint32_t nxt[3] = {0, 0, 0};
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * K; q += 8) {
+      const int li = q / K, j = q % K;
+      uint32_t cur[3] = {nxt[0], nxt[1], nxt[2]};
+      if (q + 8 < G_INST * K) fetch(q + 8, nxt);
+      int c[8];
+      float f[8];
+      if constexpr (P::ETA1 == 2) cbd2_word(cur[0], c);
+      else cbd3_words(cur[0] | (cur[1] & 0xFFu) << 16, (cur[1] >> 8) | cur[2] << 8, c);
+      i2f8(c, f);
+      f_ntt_fwd(wk[w.g], ztab, w.t, f);
+      f_put_i16(sp[li][j], w.t, f);
+    }
+  }
+  __syncthreads();
+  // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
+  {
+    struct Ops {
+      uint4 a[K];          // matrix row entries (8 int16) or 12 key bytes in x,y,z
+      uint32_t noise, msg; // PRF word for CBD2; message byte (row K only)
+    };
+    auto fetch = [&](int q, Ops& o) {
+      const int li = q / (K + 1), i = q % (K + 1);
+      const int gi = min(inst0 + li, n - 1);
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        if (i < K) {
+          o.a[j] = *reinterpret_cast<const uint4*>(mat + (size_t)gi * mat_stride + (i * K + j) * 256 + 8 * w.t);
+        } else {
+          const uint32_t* sb = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
+          o.a[j] = make_uint4(sb[0], sb[1], sb[2], 0u);
+        }
+      }
+      o.noise = *reinterpret_cast<const uint32_t*>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE + 4 * w.t);  // nonce K+i
+      o.msg = (i == K) ? small[(size_t)gi * SMALL + w.t] : 0u;
+    };
+    Ops nxt;
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * (K + 1); q += 8) {
+      const int li = q / (K + 1), i = q % (K + 1);
+      Ops cur = nxt;
+      if (q + 8 < G_INST * (K + 1)) fetch(q + 8, nxt);
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        int ai[8];
+        if (i < K) unpack8(cur.a[j], ai);
+        else frombytes12(cur.a[j].x, cur.a[j].y, cur.a[j].z, ai);
+        i2f8(ai, a);
+        f_get_i16(sp[li][j], w.t, b);
+        f_basemul_acc(acc, a, b, ztab, w.t);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+      f_ntt_inv(wk[w.g], ztab, w.t, acc);
+      int e[8], c[8];
+      cbd2_word(cur.noise, e);
+      if (i < K) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)e[k]));
+        compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
+      } else {
+        int m[8];
+        frommsg_contig(cur.msg, m);
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)(e[k] + m[k])));
+        compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
+      }
+    }
+  }
+  __syncthreads();
+  // the workgroup's ciphertexts are one contiguous run of global memory
+  const int nvalid = min(G_INST, n - inst0);
+  const uint4* src = reinterpret_cast<const uint4*>(&ctb[0][0]);
+  uint4* dst = reinterpret_cast<uint4*>(ct + (size_t)inst0 * P::CTB);
+  for (int o = threadIdx.x; o < nvalid * (P::CTB / 16); o += 256) {
+    if constexpr (CMP) {
+      uint4 x = src[o], y = dst[o];
+      if ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) atomicOr(&bad[o / (P::CTB / 16)], 1u);
+    } else {
+      dst[o] = src[o];
+    }
+  }
+  if constexpr (CMP) {
+    __syncthreads();
+    if (threadIdx.x < nvalid)
+      *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + threadIdx.x) * SMALL + 96) = bad[threadIdx.x];
+  }
+}
+
+// ------------------------------------------------------------------ decryption arithmetic
+// ref/indcpa.c:318-328: m' = tomsg(v - invntt(s^ . NTT(decompress(u))))
+template <class P>
+__global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
+                                                   size_t sk_stride, uint8_t* __restrict__ small) {
+  constexpr int K = P::K;
+  __shared__ __attribute__((aligned(16))) int16_t uh[G_INST][K][256];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ float ztab[128];
+  const Grp w = grp();
+  const int inst0 = blockIdx.x * G_INST;
+  f_twiddles_to_lds(ztab);
+
+  for (int q = w.g; q < G_INST * K; q += 8) {
+    const int li = q / K, j = q % K;
+    const int gi = min(inst0 + li, n - 1);
+    int c[8];
+    float f[8];
+    decompress_contig<P::DU>(ct + (size_t)gi * P::CTB + P::UB * j, w.t, c);
+    i2f8(c, f);
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    f_put_i16(uh[li][j], w.t, f);
+  }
+  __syncthreads();
+  {
+    const int li = w.g;  // G_INST == number of groups: one result polynomial each
+    const int gi = min(inst0 + li, n - 1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      ld_bytes12f(sk + (size_t)gi * sk_stride + 384 * j, w.t, a);
+      f_get_i16(uh[li][j], w.t, b);
+      f_basemul_acc(acc, a, b, ztab, w.t);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+    f_ntt_inv(wk[w.g], ztab, w.t, acc);
+    int v[8], c[8];
+    decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = fcanon(fred((float)v[k] - acc[k]));
+    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)tomsg_contig(c);
+  }
+}
+
+// ------------------------------------------------------------------ standalone polynomial kernels
+// (BASELINE.json config 2: batched NTT / basemul / inverse NTT on dense
+// arrays of int16[256] polynomials; 8 polynomials per 256-thread workgroup)
+__global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int c[8];
+  ld_coef8(r + pi * 256, w.t, c);
+  lds_put_contig(wk[w.g], w.t, c);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, c);
+  if (live) lds_put_contig(r + pi * 256, w.t, c);
+}
+
+__global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __restrict__ r) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int c[8];
+  ld_coef8(r + pi * 256, w.t, c);
+  ntt_inv(wk[w.g], w.t, c);
+  stride_to_contig(wk[w.g], w.t, c);
+  if (live) lds_put_contig(r + pi * 256, w.t, c);
+}
+
+// r = a o b (Montgomery domain), no reduction beyond basemul's own.  ref/poly.c:273-280
+__global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
+                                                      const int16_t* __restrict__ b) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[8], y[8];
+  ld_coef8(a + pi * 256, w.t, x);
+  ld_coef8(b + pi * 256, w.t, y);
+  basemul_acc(acc, x, y, w.t);
+  lds_put_contig(r + pi * 256, w.t, acc);
+}
+
+// fused: r = invntt_tomont( poly_ntt(a) o poly_ntt(b) ) -- one HBM round trip
+// per operand, everything else in registers/LDS.
+__global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
+                                                        const int16_t* __restrict__ b) {
+  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  const Grp w = grp();
+  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
+  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  int x[8], y[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ld_coef8(a + pi * 256, w.t, x);
+  lds_put_contig(wk[w.g], w.t, x);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, x);
+  ld_coef8(b + pi * 256, w.t, y);
+  KY_GSYNC();
+  lds_put_contig(wk[w.g], w.t, y);
+  KY_GSYNC();
+  ntt_fwd(wk[w.g], w.t, y);
+  basemul_acc(acc, x, y, w.t);
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
+  ntt_inv(wk[w.g], w.t, acc);
+  stride_to_contig(wk[w.g], w.t, acc);
+  if (live) lds_put_contig(r + pi * 256, w.t, acc);
+}
+
+}  // namespace ky

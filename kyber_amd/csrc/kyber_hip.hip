@@ -1,7 +1,8 @@
 // kyber_hip.hip -- C-ABI of libkyber_hip.so (include/kyber_batch.h,
 // include/kyber_api.h): workspace management and the kernel sequences for
 // batched keypair / encaps / decaps.  There is no CPU fallback anywhere in
-// this file: every result is produced by the gfx950 kernels in kem_kernels.h.
+// this file: every result is produced by the gfx950 kernels in kem_kernels.h,
+// kem_kernels_90s.h and arith_kernels.h (the latter through arith_launch.h).
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "../../include/kyber_batch.h"
 #include "../../include/kyber_api.h"
 #include "kem_kernels_90s.h"
+#include "arith_launch.h"
 
 using namespace ky;
 
@@ -179,7 +181,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     }
-    RUN("k_kp_arith", st, k_kp_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, L.small, L.mat, L.prf, p, s));
+    RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
     if constexpr (N90) {
       RUN("k90_kp_post", st, k90_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
     } else {
@@ -224,7 +226,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
-    RUN("k_enc_arith", st, k_enc_arith<P, false><<<blocks(m, G_INST), 256, 0, st>>>(m, p, pk_stride, L.small, mat, mat_stride, L.prf, c));
+    RUN("k_enc_arith", st, launch_enc_arith<P, false>(st, m, p, pk_stride, L.small, mat, mat_stride, L.prf, c));
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     } else {
@@ -251,7 +253,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * sk_stride;
-    RUN("k_dec_arith", st, k_dec_arith<P><<<blocks(m, G_INST), 256, 0, st>>>(m, c, s, sk_stride, L.small));
+    RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
     if constexpr (N90) {
       RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
@@ -265,8 +267,8 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
     // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
-    RUN("k_enc_arith_cmp", st, k_enc_arith<P, true><<<blocks(m, G_INST), 256, 0, st>>>(m, s + P::PVB, sk_stride, L.small, mat, mat_stride,
-                                                             L.prf, const_cast<uint8_t*>(c)));
+    RUN("k_enc_arith_cmp", st,
+        launch_enc_arith<P, true>(st, m, s + P::PVB, sk_stride, L.small, mat, mat_stride, L.prf, const_cast<uint8_t*>(c)));
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
@@ -727,25 +729,25 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, cons
 int kyber_batch_poly_ntt_dev(size_t npoly, int16_t* r, void* stream) {
   if (!r) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  RUN("k_poly_ntt", static_cast<hipStream_t>(stream), k_poly_ntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r));
+  RUN("k_poly_ntt", static_cast<hipStream_t>(stream), launch_poly_ntt(static_cast<hipStream_t>(stream), npoly, r));
   return 0;
 }
 int kyber_batch_poly_invntt_dev(size_t npoly, int16_t* r, void* stream) {
   if (!r) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  RUN("k_poly_invntt", static_cast<hipStream_t>(stream), k_poly_invntt<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r));
+  RUN("k_poly_invntt", static_cast<hipStream_t>(stream), launch_poly_invntt(static_cast<hipStream_t>(stream), npoly, r));
   return 0;
 }
 int kyber_batch_poly_basemul_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
   if (!r || !a || !b) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  RUN("k_poly_basemul", static_cast<hipStream_t>(stream), k_poly_basemul<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b));
+  RUN("k_poly_basemul", static_cast<hipStream_t>(stream), launch_poly_basemul(static_cast<hipStream_t>(stream), npoly, r, a, b));
   return 0;
 }
 int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
   if (!r || !a || !b) return KYBER_HIP_EINVAL;
   if (!npoly) return 0;
-  RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), k_poly_mul_fused<<<blocks(npoly, 8), 256, 0, static_cast<hipStream_t>(stream)>>>((long)npoly, r, a, b));
+  RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), launch_poly_mul_fused(static_cast<hipStream_t>(stream), npoly, r, a, b));
   return 0;
 }
 

@@ -32,7 +32,9 @@ class KyberHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libkyber_hip.so")
+    """In-tree libkyber_hip.so; KYBER_HIP_LIBRARY names another build of the same
+    library (A/B measurements, tools/ab_bench.sh)."""
+    return os.environ.get("KYBER_HIP_LIBRARY") or os.path.join(_HERE, "libkyber_hip.so")
 
 
 def sizes(k):
