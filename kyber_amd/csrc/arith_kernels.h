@@ -200,18 +200,19 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
 #pragma unroll
       for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
       f_ntt_inv(wk[w.g], ztab, w.t, acc);
-      int e[8], c[8];
+      int e[8];
+      unsigned c[8];
       cbd2_word(cur.noise, e);
       if (i < K) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)e[k]));
-        compress_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
+        for (int k = 0; k < 8; k++) c[k] = fcompress<P::DU>(acc[k] + (float)e[k]);  // |.| <= 1668 + 2
+        pack_bits_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
       } else {
         int m[8];
         frommsg_contig(cur.msg, m);
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + (float)(e[k] + m[k])));
-        compress_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
+        for (int k = 0; k < 8; k++) c[k] = fcompress<P::DV>(acc[k] + (float)(e[k] + m[k]));  // |.| <= 1668 + 2 + 1665
+        pack_bits_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
       }
     }
   }
@@ -272,11 +273,12 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
     f_ntt_inv(wk[w.g], ztab, w.t, acc);
-    int v[8], c[8];
+    int v[8];
     decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, v);
+    unsigned byte = 0;  // poly_tomsg: bit k = round(2 x / q) & 1       ref/poly.c:180-194
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = fcanon(fred((float)v[k] - acc[k]));
-    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)tomsg_contig(c);
+    for (int k = 0; k < 8; k++) byte |= fcompress<1>((float)v[k] - acc[k]) << k;  // |.| <= 3328 + 1668
+    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)byte;
   }
 }
 

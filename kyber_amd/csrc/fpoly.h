@@ -50,6 +50,22 @@ __device__ __forceinline__ int fcanon(float r) {
   return v + ((v >> 31) & Q);
 }
 
+// round(x * 2^D / q) mod 2^D of an integer-valued x, |x| <= 5000, ANY
+// representative of its residue class -- the reference's compression
+// ((u << D) + q/2) / q & mask of the canonical u (ref/poly.c:30,45,
+// ref/polyvec.c:26,50; D = 1 is poly_tomsg, ref/poly.c:187-190).  One FMA puts
+// x * (2^D/q) + 1.5*2^23 into a float whose low mantissa bits ARE the rounded
+// quotient in two's complement, so the result is a mask away.  Exact because
+// x * 2^D / q is never within 1/(2q) = 1.5e-4 of a rounding boundary (q is
+// odd) while the error of the rounded constant is <= |x| * 2^-25 < 1.5e-4;
+// different representatives differ by exact multiples of 2^D.  Checked
+// exhaustively in tests/test_host_logic.py.
+template <int D>
+__device__ __forceinline__ unsigned fcompress(float x) {
+  constexpr float C = (float)(1 << D) / 3329.0f;
+  return __float_as_uint(__builtin_fmaf(x, C, RND_MAGIC)) & ((1u << D) - 1);
+}
+
 // Sub-wavefront rendezvous: the 32 work-items of a polynomial group sit in one
 // wavefront, whose LDS operations are issued and completed in program order,
 // so ordering the compiler is all that is needed.

@@ -241,19 +241,27 @@ __device__ __forceinline__ int decompress1(unsigned v) {
 }
 
 // Pack the work-item's 8 coefficients into D bytes at out + D*t (LDS or global).
+// Pack the work-item's eight D-bit values into D bytes at out + D*t.
 template <int D>
-__device__ __forceinline__ void compress_contig(uint8_t* out, int t, const int (&c)[8]) {
+__device__ __forceinline__ void pack_bits_contig(uint8_t* out, int t, const unsigned (&v)[8]) {
   unsigned long long lo = 0, hi = 0;  // 8*D <= 88 bits
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    unsigned long long v = compress1<D>(c[k]);
+    const unsigned long long x = v[k];
     const int pos = D * k;
-    if (pos < 64) lo |= v << pos;
-    if (pos + D > 64) hi |= (pos >= 64) ? v << (pos - 64) : v >> (64 - pos);
+    if (pos < 64) lo |= x << pos;
+    if (pos + D > 64) hi |= (pos >= 64) ? x << (pos - 64) : x >> (64 - pos);
   }
   uint8_t* o = out + D * t;
 #pragma unroll
   for (int b = 0; b < D; b++) o[b] = (uint8_t)(b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8)));
+}
+template <int D>
+__device__ __forceinline__ void compress_contig(uint8_t* out, int t, const int (&c)[8]) {
+  unsigned v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = compress1<D>(c[k]);
+  pack_bits_contig<D>(out, t, v);
 }
 // Unpack D bytes at in + D*t into the work-item's 8 coefficients.
 template <int D>

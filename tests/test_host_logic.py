@@ -86,3 +86,22 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_float_compress_formula_is_exact():
+    """fpoly.h fcompress<D>: low D mantissa bits of fl32(x * fl32(2^D/q) + 1.5*2^23)
+    equal the reference's ((u << D) + q/2) / q & mask (ref/poly.c:30,45,187-190,
+    ref/polyvec.c:26,50) for every integer x in [-5000, 5000], u = x mod q.
+    The single-rounding FMA is reproduced in float64 (the sum is exact there)."""
+    q = 3329
+    x = np.arange(-5000, 5001, dtype=np.int64)
+    u = x % q
+    for d in (1, 4, 5, 10, 11):
+        c = np.float32(np.float32(1 << d) / np.float32(q))
+        y = (x.astype(np.float64) * np.float64(c) + 12582912.0).astype(np.float32)
+        got = y.view(np.uint32) & ((1 << d) - 1)
+        want = (((u << d) + q // 2) // q) & ((1 << d) - 1)
+        assert np.array_equal(got, want), d
+        # distance to the nearest rounding boundary really exceeds the constant's error
+        frac = (u.astype(np.float64) * (1 << d) / q) % 1.0
+        assert np.min(np.abs(frac[u != 0] - 0.5)) > 1.49e-4
