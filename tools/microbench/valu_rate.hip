@@ -142,11 +142,29 @@ KERNEL(k_cvtif, A_CVTIF)
 KERNEL(k_floor, A_FLOOR)
 KERNEL(k_fract, A_FRACT)
 
+#define A_FMAMIX(n) "v_fma_mix_f32 %" #n ", %8, %9, %" #n " op_sel_hi:[1,0,0]\n"
+#define A_FMAMIXHI(n) "v_fma_mix_f32 %" #n ", %8, %9, %" #n " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define A_CVTF16(n) "v_cvt_f32_f16 %" #n ", %" #n "\n"
+#define A_CVTF16HI(n) "v_cvt_f32_f16_sdwa %" #n ", %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define A_CVTI16HI(n) "v_cvt_f32_i32_sdwa %" #n ", sext(%" #n ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define A_CVTPKRTZ(n) "v_cvt_pkrtz_f16_f32 %" #n ", %" #n ", %8\n"
+#define A_CVTUB(n) "v_cvt_f32_ubyte1 %" #n ", %" #n "\n"
+#define A_PKFMA(n) "v_pk_fma_f32 %[p" #n "], %[p" #n "], %[pa], %[pb]\n"
+KERNEL(k_fmamix, A_FMAMIX)
+KERNEL(k_fmamixhi, A_FMAMIXHI)
+KERNEL(k_cvtf16, A_CVTF16)
+KERNEL(k_cvtf16hi, A_CVTF16HI)
+KERNEL(k_cvti16hi, A_CVTI16HI)
+KERNEL(k_cvtpkrtz, A_CVTPKRTZ)
+KERNEL(k_cvtub, A_CVTUB)
+
 typedef void (*kfn)(uint32_t*, unsigned long long*, int);
 struct V { const char* name; kfn f; };
 
 int main() {
-  V vs[] = {{"v_mul_f32", k_fmul}, {"v_add_f32", k_fadd}, {"v_fma_f32", k_ffma}, {"v_fmac_f32", k_fmac}, {"v_rndne_f32", k_rndne},
+  V vs[] = {{"v_fma_mix_f32 lo", k_fmamix}, {"v_fma_mix_f32 hi", k_fmamixhi}, {"v_cvt_f32_f16", k_cvtf16}, {"v_cvt_f32_f16 W1", k_cvtf16hi},
+            {"v_cvt_f32_i32 W1", k_cvti16hi}, {"v_cvt_pkrtz_f16", k_cvtpkrtz}, {"v_cvt_f32_ubyte1", k_cvtub},
+            {"v_mul_f32", k_fmul}, {"v_add_f32", k_fadd}, {"v_fma_f32", k_ffma}, {"v_fmac_f32", k_fmac}, {"v_rndne_f32", k_rndne},
             {"v_cvt_f32_i32", k_cvtfi}, {"v_cvt_i32_f32", k_cvtif}, {"v_floor_f32", k_floor}, {"v_fract_f32", k_fract},
             {"v_xor_b32(e32)", k_xor}, {"v_xor_b32(e64)", k_xor_e64}, {"v_bitop3 0x96", k_bitop3}, {"v_bitop3 0xd2", k_bitop3d2},
             {"v_alignbit", k_alignbit}, {"v_bfi", k_bfi}, {"v_or3", k_or3}, {"v_mul_i32_i24", k_muli24}, {"v_mad_i32_i24", k_madi24},
