@@ -156,6 +156,15 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t *r, const int16_t *a, c
  * A^T (transposed = 1) expanded from seeds[i][32].        ref/indcpa.c:164-192 */
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, const uint8_t *seeds, int transposed, void *stream);
 
+/* ---- pinned host memory (optional) ----
+ * The host-pointer entry points overlap PCIe copies with the kernels; the
+ * copies are true DMA only from page-locked memory.  Buffers from
+ * kyber_hip_host_alloc (hipHostMalloc) give the full rate, any other host
+ * memory works at the runtime's staged-copy rate.  No counterpart in the
+ * reference, whose buffers are plain arrays. */
+void *kyber_hip_host_alloc(size_t bytes);
+void kyber_hip_host_free(void *p);
+
 /* ---- housekeeping ---- */
 /* instances processed per internal pass (workspace sizing); 0 restores the default */
 int kyber_hip_set_chunk(size_t instances);

@@ -406,32 +406,141 @@ struct DevBuf {
   }
 };
 
-int fill_coins(uint8_t* dst_dev, const uint8_t* coins, size_t bytes) {
-  if (coins) {
-    HIP_TRY(hipMemcpy(dst_dev, coins, bytes, hipMemcpyHostToDevice));
+// ---- host-pointer pipelines ------------------------------------------------------
+// A host batch is cut into passes of HOST_PASS instances that flow through three
+// streams -- copy in, compute, copy out -- with two device staging slots, so the
+// PCIe transfers of neighbouring passes overlap the kernels of the current one.
+// With pinned host memory (kyber_hip_host_alloc, hipHostMalloc, hipHostRegister)
+// the copies are true DMA; with pageable memory the runtime stages them and the
+// calls are merely correct.
+constexpr size_t HOST_PASS = 1u << 15;
+
+struct HostIn {
+  const uint8_t* p;
+  size_t per;   // bytes per instance
+  bool once;    // one record for the whole batch (shared key), copied before the first pass
+};
+struct HostOut {
+  uint8_t* p;
+  size_t per;
+};
+
+struct Streams {
+  hipStream_t in = nullptr, comp = nullptr, out = nullptr;
+  hipEvent_t in_done[2] = {}, comp_done[2] = {}, out_done[2] = {};
+  bool ok = false;
+  int init() {
+    HIP_TRY(hipStreamCreateWithFlags(&in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&comp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&out, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) {
+      HIP_TRY(hipEventCreateWithFlags(&in_done[s], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&comp_done[s], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&out_done[s], hipEventDisableTiming));
+    }
+    ok = true;
     return 0;
   }
-  uint8_t* tmp = static_cast<uint8_t*>(malloc(bytes ? bytes : 1));
-  if (!tmp) return KYBER_HIP_EINVAL;
-  randombytes(tmp, bytes);
-  hipError_t e = hipMemcpy(dst_dev, tmp, bytes, hipMemcpyHostToDevice);
-  memset(tmp, 0, bytes);
-  free(tmp);
-  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(coins)");
+  ~Streams() {
+    if (in) (void)hipStreamDestroy(in);
+    if (comp) (void)hipStreamDestroy(comp);
+    if (out) (void)hipStreamDestroy(out);
+    for (int s = 0; s < 2; s++) {
+      if (in_done[s]) (void)hipEventDestroy(in_done[s]);
+      if (comp_done[s]) (void)hipEventDestroy(comp_done[s]);
+      if (out_done[s]) (void)hipEventDestroy(out_done[s]);
+    }
+  }
+};
+
+// f(m, in[], out[], stream): the device-pointer routine for one pass of m instances
+template <class F>
+int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer_list<HostOut> outs_, F&& f) {
+  const std::vector<HostIn> ins(ins_);
+  const std::vector<HostOut> outs(outs_);
+  const size_t pass = n < HOST_PASS ? n : HOST_PASS;
+  const int slots = n > pass ? 2 : 1;
+  Streams S;
+  if (int rc = S.init()) return rc;
+  // one allocation holds every staging buffer of every slot (256-byte aligned pieces)
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t total = 0;
+  for (auto& a : ins) total += a.once ? pad(a.per) : slots * pad(a.per * pass);
+  for (auto& a : outs) total += slots * pad(a.per * pass);
+  DevBuf all;
+  if (int rc = all.alloc(total)) return rc;
+  std::vector<uint8_t*> din[2], dout[2];
+  uint8_t* cur = all.p;
+  for (int s = 0; s < 2; s++) {
+    din[s].resize(ins.size());
+    dout[s].resize(outs.size());
+  }
+  for (size_t i = 0; i < ins.size(); i++) {
+    if (ins[i].once) {
+      din[0][i] = din[1][i] = cur;
+      cur += pad(ins[i].per);
+      HIP_TRY(hipMemcpyAsync(din[0][i], ins[i].p, ins[i].per, hipMemcpyHostToDevice, S.in));
+    } else {
+      for (int s = 0; s < slots; s++) {
+        din[s][i] = cur;
+        cur += pad(ins[i].per * pass);
+      }
+    }
+  }
+  for (size_t i = 0; i < outs.size(); i++)
+    for (int s = 0; s < slots; s++) {
+      dout[s][i] = cur;
+      cur += pad(outs[i].per * pass);
+    }
+  size_t c = 0;
+  for (size_t o = 0; o < n; o += pass, c++) {
+    const size_t m = n - o < pass ? n - o : pass;
+    const int s = (int)(c & 1) % slots;
+    if (c >= 2) HIP_TRY(hipStreamWaitEvent(S.in, S.comp_done[s], 0));  // slot's inputs consumed
+    for (size_t i = 0; i < ins.size(); i++)
+      if (!ins[i].once)
+        HIP_TRY(hipMemcpyAsync(din[s][i], ins[i].p + o * ins[i].per, m * ins[i].per, hipMemcpyHostToDevice, S.in));
+    HIP_TRY(hipEventRecord(S.in_done[s], S.in));
+    HIP_TRY(hipStreamWaitEvent(S.comp, S.in_done[s], 0));
+    if (c >= 2) HIP_TRY(hipStreamWaitEvent(S.comp, S.out_done[s], 0));  // slot's outputs drained
+    if (int rc = f(m, din[s].data(), dout[s].data(), S.comp)) {
+      (void)hipDeviceSynchronize();
+      return rc;
+    }
+    HIP_TRY(hipEventRecord(S.comp_done[s], S.comp));
+    HIP_TRY(hipStreamWaitEvent(S.out, S.comp_done[s], 0));
+    for (size_t i = 0; i < outs.size(); i++)
+      HIP_TRY(hipMemcpyAsync(outs[i].p + o * outs[i].per, dout[s][i], m * outs[i].per, hipMemcpyDeviceToHost, S.out));
+    HIP_TRY(hipEventRecord(S.out_done[s], S.out));
+  }
+  HIP_TRY(hipStreamSynchronize(S.out));
+  HIP_TRY(hipStreamSynchronize(S.comp));
+  HIP_TRY(hipStreamSynchronize(S.in));
   return 0;
 }
 
+// coins == NULL: draw them from randombytes (zeroised afterwards)
+struct Coins {
+  std::vector<uint8_t> own;
+  const uint8_t* p;
+  Coins(const uint8_t* given, size_t bytes) : p(given) {
+    if (!given) {
+      own.resize(bytes ? bytes : 1);
+      randombytes(own.data(), bytes);
+      p = own.data();
+    }
+  }
+  ~Coins() {
+    if (!own.empty()) memset(own.data(), 0, own.size());
+  }
+};
+
 template <class P, bool N90>
 int keypair_host(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins) {
-  DevBuf dpk, dsk, dc;
-  if (int rc = dpk.alloc(n * P::PKB)) return rc;
-  if (int rc = dsk.alloc(n * P::SKB)) return rc;
-  if (int rc = dc.alloc(n * 64)) return rc;
-  if (int rc = fill_coins(dc.p, coins, n * 64)) return rc;
-  if (int rc = keypair_dev<P, N90>(n, dpk.p, dsk.p, dc.p, nullptr)) return rc;
-  HIP_TRY(hipMemcpy(pk, dpk.p, n * P::PKB, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(sk, dsk.p, n * P::SKB, hipMemcpyDeviceToHost));
-  return 0;
+  Coins c(coins, n * 64);
+  return host_pipeline(n, {{c.p, 64, false}}, {{pk, P::PKB}, {sk, P::SKB}}, [](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+    return keypair_dev<P, N90>(m, out[0], out[1], in[0], st);
+  });
 }
 
 template <class P, bool N90>
@@ -453,32 +562,19 @@ int dec_shared_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, 
 
 template <class P, bool N90>
 int enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, bool shared) {
-  DevBuf dpk, dct, dss, dc;
-  const size_t nkeys = shared ? 1 : n;
-  if (int rc = dpk.alloc(nkeys * P::PKB)) return rc;
-  if (int rc = dct.alloc(n * P::CTB)) return rc;
-  if (int rc = dss.alloc(n * 32)) return rc;
-  if (int rc = dc.alloc(n * 32)) return rc;
-  HIP_TRY(hipMemcpy(dpk.p, pk, nkeys * P::PKB, hipMemcpyHostToDevice));
-  if (int rc = fill_coins(dc.p, coins, n * 32)) return rc;
-  if (int rc = enc_dev<P, N90>(n, dct.p, dss.p, dpk.p, shared ? 0 : P::PKB, dc.p, nullptr)) return rc;
-  HIP_TRY(hipMemcpy(ct, dct.p, n * P::CTB, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
-  return 0;
+  Coins c(coins, n * 32);
+  return host_pipeline(n, {{pk, P::PKB, shared}, {c.p, 32, false}}, {{ct, P::CTB}, {ss, 32}},
+                       [shared](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+                         return enc_dev<P, N90>(m, out[0], out[1], in[0], shared ? 0 : P::PKB, in[1], st);
+                       });
 }
 
 template <class P, bool N90>
 int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, bool shared) {
-  DevBuf dsk, dct, dss;
-  const size_t nkeys = shared ? 1 : n;
-  if (int rc = dsk.alloc(nkeys * P::SKB)) return rc;
-  if (int rc = dct.alloc(n * P::CTB)) return rc;
-  if (int rc = dss.alloc(n * 32)) return rc;
-  HIP_TRY(hipMemcpy(dsk.p, sk, nkeys * P::SKB, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dct.p, ct, n * P::CTB, hipMemcpyHostToDevice));
-  if (int rc = dec_dev<P, N90>(n, dss.p, dct.p, dsk.p, shared ? 0 : P::SKB, nullptr)) return rc;
-  HIP_TRY(hipMemcpy(ss, dss.p, n * 32, hipMemcpyDeviceToHost));
-  return 0;
+  return host_pipeline(n, {{ct, P::CTB, false}, {sk, P::SKB, shared}}, {{ss, 32}},
+                       [shared](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+                         return dec_dev<P, N90>(m, out[0], in[0], in[1], shared ? 0 : P::SKB, st);
+                       });
 }
 
 // Host-pointer form of a device-pointer routine: stage every argument in device
@@ -507,22 +603,6 @@ int with_device(std::initializer_list<HostArg> args, F&& f) {
   }
   return 0;
 }
-
-// coins == NULL: draw them from randombytes (zeroised afterwards)
-struct Coins {
-  std::vector<uint8_t> own;
-  const uint8_t* p;
-  Coins(const uint8_t* given, size_t bytes) : p(given) {
-    if (!given) {
-      own.resize(bytes ? bytes : 1);
-      randombytes(own.data(), bytes);
-      p = own.data();
-    }
-  }
-  ~Coins() {
-    if (!own.empty()) memset(own.data(), 0, own.size());
-  }
-};
 
 template <class P, bool N90>
 int kex_initA_host(size_t n, uint8_t* send, uint8_t* tk, uint8_t* sk, const uint8_t* pkb, const uint8_t* coins, int shared_b) {
@@ -749,6 +829,15 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, c
   if (!npoly) return 0;
   RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), launch_poly_mul_fused(static_cast<hipStream_t>(stream), npoly, r, a, b));
   return 0;
+}
+
+void* kyber_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void kyber_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int kyber_hip_set_chunk(size_t instances) {

@@ -77,6 +77,8 @@ def library():
         "kyber_hip_profile_read": [ctypes.c_char_p, sz],
         "kyber_hip_release": [],
     }
+    lib.kyber_hip_host_alloc.argtypes, lib.kyber_hip_host_alloc.restype = [sz], ctypes.c_void_p
+    lib.kyber_hip_host_free.argtypes, lib.kyber_hip_host_free.restype = [ctypes.c_void_p], None
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -274,6 +276,31 @@ def profile_read():
 
 def set_chunk(instances):
     _check(library().kyber_hip_set_chunk(int(instances)), "kyber_hip_set_chunk")
+
+
+class _Pinned:
+    def __init__(self, nbytes):
+        self.lib = library()
+        self.ptr = self.lib.kyber_hip_host_alloc(nbytes)
+        if not self.ptr:
+            raise KyberHipError("kyber_hip_host_alloc(%d) failed" % nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.lib.kyber_hip_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape):
+    """uint8 numpy array in page-locked host memory (kyber_hip_host_alloc); the
+    host-pointer calls reach full PCIe rate on such arrays.  The memory is
+    released when the array (and every view of it) is gone."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    n = int(np.prod(shape)) if shape else 1
+    owner = _Pinned(max(n, 1))
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(owner.ptr)
+    buf._pin = owner  # the array's base object keeps the allocation alive
+    return np.frombuffer(buf, dtype=np.uint8, count=n).reshape(shape)
 
 
 def set_tail_capacity(records=None):

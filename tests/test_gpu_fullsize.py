@@ -58,3 +58,39 @@ def test_ntt_roundtrip_one_million_polys():
     kl.poly_invntt_(r)
     want = (a.to(torch.int32) * ((1 << 16) % Q)) % Q
     assert torch.equal(r.to(torch.int32) % Q, want)
+
+
+def test_host_pipeline_multi_pass_pinned_and_pageable(oracle):
+    """Host-pointer entry points on a batch that spans several copy/compute
+    passes (HOST_PASS = 2^15, ragged last pass), from pinned and from pageable
+    memory: same bytes as the device-pointer path, strided sample vs the oracle."""
+    import torch
+    from kyber_amd import lib as kl
+    k, n = 3, 3 * 32768 + 777
+    kem = kyber_amd.KyberHip(k)
+    rng = np.random.default_rng(2718)
+    kc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ec = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = kem.keypair(kc)
+    ct, ss = kem.enc(pk, ec)
+    ss2 = kem.dec(ct, sk)
+    assert np.array_equal(ss, ss2)
+    dev = torch.device("cuda", 0)
+    dpk, dsk = kem.keypair_dev(torch.from_numpy(kc).to(dev))
+    dct, dss = kem.enc_dev(dpk, torch.from_numpy(ec).to(dev))
+    assert np.array_equal(dpk.cpu().numpy(), pk) and np.array_equal(dsk.cpu().numpy(), sk)
+    assert np.array_equal(dct.cpu().numpy(), ct) and np.array_equal(dss.cpu().numpy(), ss)
+    idx = np.arange(0, n, 1571)
+    opk, osk = oracle.keypair(k, kc[idx])
+    oct_, oss = oracle.enc(k, opk, ec[idx])
+    assert np.array_equal(pk[idx], opk) and np.array_equal(sk[idx], osk)
+    assert np.array_equal(ct[idx], oct_) and np.array_equal(ss[idx], oss)
+    # pinned buffers, shared-key variants across passes
+    ppk, pec = kl.pinned_empty(pk.shape), kl.pinned_empty(ec.shape)
+    ppk[:], pec[:] = pk, ec
+    pct, pss = kem.enc(ppk, pec)
+    assert np.array_equal(pct, ct) and np.array_equal(pss, ss)
+    sct, sss = kem.enc_shared_pk(pk[5], ec)
+    assert np.array_equal(kem.dec_shared_sk(sct, sk[5]), sss)
+    assert np.array_equal(sct[idx], oracle.enc(k, np.tile(pk[5], (len(idx), 1)), ec[idx])[0])
+    del ppk, pec
