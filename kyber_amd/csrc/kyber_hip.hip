@@ -453,24 +453,62 @@ struct Streams {
   }
 };
 
+// Streams, events and the staging allocation are kept per device between calls
+// (small batches would otherwise spend most of their time creating them); host
+// calls on one device are serialised by g_host_mu.
+struct HostCtx {
+  Streams S;
+  uint8_t* staging = nullptr;
+  size_t cap = 0;
+};
+HostCtx* g_host[MAX_DEV] = {};
+std::mutex g_host_mu;
+
+int host_ctx(size_t bytes, HostCtx** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
+  if (!g_host[dev]) {
+    HostCtx* c = new HostCtx();
+    if (int rc = c->S.init()) {
+      delete c;
+      return rc;
+    }
+    g_host[dev] = c;
+  }
+  HostCtx* c = g_host[dev];
+  if (c->cap < bytes) {
+    if (c->staging) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(c->staging));
+      c->staging = nullptr;
+      c->cap = 0;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->staging), bytes));
+    c->cap = bytes;
+  }
+  *out = c;
+  return 0;
+}
+
 // f(m, in[], out[], stream): the device-pointer routine for one pass of m instances
 template <class F>
 int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer_list<HostOut> outs_, F&& f) {
+  std::lock_guard<std::mutex> hlk(g_host_mu);
   const std::vector<HostIn> ins(ins_);
   const std::vector<HostOut> outs(outs_);
   const size_t pass = n < HOST_PASS ? n : HOST_PASS;
   const int slots = n > pass ? 2 : 1;
-  Streams S;
-  if (int rc = S.init()) return rc;
   // one allocation holds every staging buffer of every slot (256-byte aligned pieces)
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t total = 0;
   for (auto& a : ins) total += a.once ? pad(a.per) : slots * pad(a.per * pass);
   for (auto& a : outs) total += slots * pad(a.per * pass);
-  DevBuf all;
-  if (int rc = all.alloc(total)) return rc;
+  HostCtx* ctx = nullptr;
+  if (int rc = host_ctx(total, &ctx)) return rc;
+  Streams& S = ctx->S;
   std::vector<uint8_t*> din[2], dout[2];
-  uint8_t* cur = all.p;
+  uint8_t* cur = ctx->staging;
   for (int s = 0; s < 2; s++) {
     din[s].resize(ins.size());
     dout[s].resize(outs.size());
@@ -853,6 +891,7 @@ int kyber_hip_set_tail_capacity(size_t records) {
 }
 
 int kyber_hip_release(void) {
+  std::lock_guard<std::mutex> hlk(g_host_mu);  // same order as the host-pointer calls: host lock, then workspace lock
   std::lock_guard<std::mutex> lk(g_mu);
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -861,6 +900,12 @@ int kyber_hip_release(void) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(g_ws[dev].base));
     g_ws[dev] = Workspace{};
+  }
+  if (HostCtx* c = g_host[dev]) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->staging) HIP_TRY(hipFree(c->staging));
+    delete c;  // streams and events
+    g_host[dev] = nullptr;
   }
   return 0;
 }
