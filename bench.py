@@ -199,7 +199,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun, also with one rank, so the RCCL path can be rehearsed on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -302,7 +302,7 @@ def main():
         out = {
             "metric": "%s encaps+decaps/sec%s" % (set_name, " (one shared key pair)" if args.shared_key else ""), "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16/u64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (Keccak lanes as 2x32 bit) + f32 (exact integer polynomial arithmetic)",
             "data": "synthetic (device-generated coins, seed 0x4B59424552)",
             "config": {"workload": "%s batched encaps+decaps%s, %d instances per GPU per step, device-resident"
                        % (set_name, " with one shared key pair" if args.shared_key else "", n),
