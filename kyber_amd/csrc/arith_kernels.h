@@ -285,16 +285,23 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
 // ------------------------------------------------------------------ standalone polynomial kernels
 // (BASELINE.json config 2: batched NTT / basemul / inverse NTT on dense
 // arrays of int16[256] polynomials; 8 polynomials per 256-thread workgroup)
+// (The fp32 engine was tried for k_poly_ntt, whose Barrett-centred output depends
+// on residues only: 3.45 G NTT/s against 4.0 G/s for this int16 version, whose
+// LDS tiles are half the size.  invntt_tomont and basemul must stay integer in
+// any case: their Montgomery-path representatives in (-q, q) depend on the
+// integer arithmetic itself.)
 __global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ int16_t ztab[128];
   const Grp w = grp();
   const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
   const bool live = (long)blockIdx.x * 8 + w.g < npoly;
   int c[8];
   ld_coef8(r + pi * 256, w.t, c);
+  twiddles_to_lds(ztab);
   lds_put_contig(wk[w.g], w.t, c);
   KY_GSYNC();
-  ntt_fwd(wk[w.g], w.t, c);
+  ntt_fwd(wk[w.g], ztab, w.t, c);
   if (live) lds_put_contig(r + pi * 256, w.t, c);
 }
 
@@ -303,9 +310,11 @@ __global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __rest
   const Grp w = grp();
   const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
   const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  __shared__ int16_t ztab[128];
   int c[8];
   ld_coef8(r + pi * 256, w.t, c);
-  ntt_inv(wk[w.g], w.t, c);
+  twiddles_to_lds(ztab);
+  ntt_inv(wk[w.g], ztab, w.t, c);
   stride_to_contig(wk[w.g], w.t, c);
   if (live) lds_put_contig(r + pi * 256, w.t, c);
 }
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __res
   int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[8], y[8];
   ld_coef8(a + pi * 256, w.t, x);
   ld_coef8(b + pi * 256, w.t, y);
-  basemul_acc(acc, x, y, w.t);
+  basemul_acc(acc, x, y, ZETAS, w.t);
   lds_put_contig(r + pi * 256, w.t, acc);
 }
 
@@ -331,20 +340,22 @@ __global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* __r
   const Grp w = grp();
   const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
   const bool live = (long)blockIdx.x * 8 + w.g < npoly;
+  __shared__ int16_t ztab[128];
   int x[8], y[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ld_coef8(a + pi * 256, w.t, x);
+  ld_coef8(b + pi * 256, w.t, y);  // both operands in flight before the first transform
+  twiddles_to_lds(ztab);
   lds_put_contig(wk[w.g], w.t, x);
   KY_GSYNC();
-  ntt_fwd(wk[w.g], w.t, x);
-  ld_coef8(b + pi * 256, w.t, y);
+  ntt_fwd(wk[w.g], ztab, w.t, x);
   KY_GSYNC();
   lds_put_contig(wk[w.g], w.t, y);
   KY_GSYNC();
-  ntt_fwd(wk[w.g], w.t, y);
-  basemul_acc(acc, x, y, w.t);
+  ntt_fwd(wk[w.g], ztab, w.t, y);
+  basemul_acc(acc, x, y, ztab, w.t);
 #pragma unroll
   for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
-  ntt_inv(wk[w.g], w.t, acc);
+  ntt_inv(wk[w.g], ztab, w.t, acc);
   stride_to_contig(wk[w.g], w.t, acc);
   if (live) lds_put_contig(r + pi * 256, w.t, acc);
 }

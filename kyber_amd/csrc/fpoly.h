@@ -66,15 +66,6 @@ __device__ __forceinline__ unsigned fcompress(float x) {
   return __float_as_uint(__builtin_fmaf(x, C, RND_MAGIC)) & ((1u << D) - 1);
 }
 
-// Sub-wavefront rendezvous: the 32 work-items of a polynomial group sit in one
-// wavefront, whose LDS operations are issued and completed in program order,
-// so ordering the compiler is all that is needed.
-#define KY_WSYNC()                                            \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
-    __builtin_amdgcn_wave_barrier();                          \
-  } while (0)
-
 // ---------------------------------------------------------------- LDS maps (fp32, swizzled)
 // element i lives at i ^ ((i >> 5) << 2): STRIDE, MIDDLE and CONTIG accesses
 // then each touch 32 distinct banks per 32-lane group.

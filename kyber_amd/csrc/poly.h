@@ -18,9 +18,22 @@
 
 namespace ky {
 
-// Group-wide rendezvous between passes.  Every work-item of the workgroup
-// takes the same number of transforms, so a workgroup barrier is legal here.
-#define KY_GSYNC() __syncthreads()
+// Rendezvous of the 32 work-items of one polynomial between passes.  They sit
+// in one wavefront, whose LDS operations are issued and completed in program
+// order, so ordering the compiler is all that is needed.
+#define KY_WSYNC()                                            \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+  } while (0)
+#define KY_GSYNC() KY_WSYNC()
+
+// Twiddles in LDS for the lane-dependent look-ups (a vector load from the
+// constant table costs an L1/L2 round trip per look-up).
+__device__ __forceinline__ void twiddles_to_lds(int16_t* Z) {
+  if (threadIdx.x < 128) Z[threadIdx.x] = ZETAS[threadIdx.x];
+  __syncthreads();
+}
 
 // ---------------------------------------------------------------- butterflies
 __device__ __forceinline__ void ct_bf(int& a, int& b, int z) {  // ref/ntt.c:89-91
@@ -75,7 +88,7 @@ __device__ __forceinline__ void lds_get_middle(const int16_t* p, int t, int (&c)
 // in : polynomial in LDS buffer p (natural order), all 32 work-items arrived
 // out: c[] in CONTIG map, Barrett-reduced (= ref/poly.c:244-248 poly_ntt);
 //      p is left holding garbage from the intermediate passes.
-__device__ __forceinline__ void ntt_fwd(int16_t* p, int t, int (&c)[8]) {
+__device__ __forceinline__ void ntt_fwd(int16_t* p, const int16_t* Z, int t, int (&c)[8]) {
   lds_get_stride(p, t, c);
 #pragma unroll
   for (int m = 0; m < 4; m++) ct_bf(c[m], c[m + 4], ZETAS[1]);
@@ -89,21 +102,21 @@ __device__ __forceinline__ void ntt_fwd(int16_t* p, int t, int (&c)[8]) {
   lds_get_middle(p, t, c);
   {
     const int hi = t >> 2;
-    int z = ZETAS[8 + hi];
+    int z = Z[8 + hi];
 #pragma unroll
     for (int m = 0; m < 4; m++) ct_bf(c[m], c[m + 4], z);
-    int z0 = ZETAS[16 + 2 * hi], z1 = ZETAS[17 + 2 * hi];
+    int z0 = Z[16 + 2 * hi], z1 = Z[17 + 2 * hi];
     ct_bf(c[0], c[2], z0); ct_bf(c[1], c[3], z0);
     ct_bf(c[4], c[6], z1); ct_bf(c[5], c[7], z1);
-    ct_bf(c[0], c[1], ZETAS[32 + 4 * hi]); ct_bf(c[2], c[3], ZETAS[33 + 4 * hi]);
-    ct_bf(c[4], c[5], ZETAS[34 + 4 * hi]); ct_bf(c[6], c[7], ZETAS[35 + 4 * hi]);
+    ct_bf(c[0], c[1], Z[32 + 4 * hi]); ct_bf(c[2], c[3], Z[33 + 4 * hi]);
+    ct_bf(c[4], c[5], Z[34 + 4 * hi]); ct_bf(c[6], c[7], Z[35 + 4 * hi]);
   }
   KY_GSYNC();
   lds_put_middle(p, t, c);
   KY_GSYNC();
   lds_get_contig(p, t, c);
   {
-    int z0 = ZETAS[64 + 2 * t], z1 = ZETAS[65 + 2 * t];
+    int z0 = Z[64 + 2 * t], z1 = Z[65 + 2 * t];
     ct_bf(c[0], c[2], z0); ct_bf(c[1], c[3], z0);
     ct_bf(c[4], c[6], z1); ct_bf(c[5], c[7], z1);
   }
@@ -115,9 +128,9 @@ __device__ __forceinline__ void ntt_fwd(int16_t* p, int t, int (&c)[8]) {
 // in : c[] in CONTIG map (NTT domain), p = scratch LDS buffer of the group
 // out: c[] in STRIDE map, multiplied by the Montgomery factor
 //      (= ref/ntt.c:106-126 invntt, "invntt_tomont")
-__device__ __forceinline__ void ntt_inv(int16_t* p, int t, int (&c)[8]) {
+__device__ __forceinline__ void ntt_inv(int16_t* p, const int16_t* Z, int t, int (&c)[8]) {
   {
-    int z0 = ZETAS[127 - 2 * t], z1 = ZETAS[126 - 2 * t];
+    int z0 = Z[127 - 2 * t], z1 = Z[126 - 2 * t];
     gs_bf(c[0], c[2], z0); gs_bf(c[1], c[3], z0);
     gs_bf(c[4], c[6], z1); gs_bf(c[5], c[7], z1);
   }
@@ -127,12 +140,12 @@ __device__ __forceinline__ void ntt_inv(int16_t* p, int t, int (&c)[8]) {
   lds_get_middle(p, t, c);
   {
     const int hi = t >> 2;
-    gs_bf(c[0], c[1], ZETAS[63 - 4 * hi]); gs_bf(c[2], c[3], ZETAS[62 - 4 * hi]);
-    gs_bf(c[4], c[5], ZETAS[61 - 4 * hi]); gs_bf(c[6], c[7], ZETAS[60 - 4 * hi]);
-    int za = ZETAS[31 - 2 * hi], zb = ZETAS[30 - 2 * hi];
+    gs_bf(c[0], c[1], Z[63 - 4 * hi]); gs_bf(c[2], c[3], Z[62 - 4 * hi]);
+    gs_bf(c[4], c[5], Z[61 - 4 * hi]); gs_bf(c[6], c[7], Z[60 - 4 * hi]);
+    int za = Z[31 - 2 * hi], zb = Z[30 - 2 * hi];
     gs_bf(c[0], c[2], za); gs_bf(c[1], c[3], za);
     gs_bf(c[4], c[6], zb); gs_bf(c[5], c[7], zb);
-    int z = ZETAS[15 - hi];
+    int z = Z[15 - hi];
 #pragma unroll
     for (int m = 0; m < 4; m++) gs_bf(c[m], c[m + 4], z);
   }
@@ -162,10 +175,10 @@ __device__ __forceinline__ void stride_to_contig(int16_t* p, int t, int (&c)[8])
 // acc[] += a[] o b[] for the work-item's 8 CONTIG coefficients: two products in
 // Z_q[X]/(X^2 - zeta) and two in Z_q[X]/(X^2 + zeta).  ref/ntt.c:139-146 as
 // driven by ref/poly.c:273-280; summation as ref/polyvec.c:194-198.
-__device__ __forceinline__ void basemul_acc(int (&acc)[8], const int (&a)[8], const int (&b)[8], int t) {
+__device__ __forceinline__ void basemul_acc(int (&acc)[8], const int (&a)[8], const int (&b)[8], const int16_t* Z, int t) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
-    int z = ZETAS[64 + 2 * t + g];
+    int z = Z[64 + 2 * t + g];
     const int o = 4 * g;
     acc[o + 0] += fqmul(fqmul(a[o + 1], b[o + 1]), z) + fqmul(a[o + 0], b[o + 0]);
     acc[o + 1] += fqmul(a[o + 0], b[o + 1]) + fqmul(a[o + 1], b[o + 0]);

@@ -54,6 +54,22 @@ def test_gen_matrix_ragged_job_count(oracle):
             assert np.array_equal(got[i], oracle.gen_matrix(3, seeds[i], 1)[0])
 
 
+def test_poly_ntt_wide_inputs_and_extremes(oracle):
+    """poly_ntt on inputs up to 2q in magnitude (the widest for which the
+    reference's int16 butterflies cannot overflow: 2q + 7q < 2^15) and on the
+    constant extremes; the output must be the Barrett-centred representative."""
+    rng = np.random.default_rng(99)
+    a = rng.integers(-2 * Q, 2 * Q + 1, (257, 256)).astype(np.int16)
+    a[0, :] = 2 * Q
+    a[1, :] = -2 * Q
+    a[2, :] = 0
+    a[3, ::2], a[3, 1::2] = Q - 1, -(Q - 1)
+    got = kl.poly_ntt_(_dev(a)).cpu().numpy()
+    want = oracle.poly_op("ko_poly_ntt", a)
+    assert np.array_equal(got, want)
+    assert got.min() >= -(Q - 1) // 2 and got.max() <= (Q - 1) // 2
+
+
 @pytest.mark.parametrize("npoly", [1, 8, 13, 1000])
 def test_poly_ntt_invntt_basemul(oracle, npoly):
     rng = np.random.default_rng(npoly)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Latency of small host-pointer batches (the reference-shaped batch-of-one API
+and small n): microseconds per call, median of 200."""
+import ctypes
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import kyber_amd  # noqa: E402
+from kyber_amd import lib as kl  # noqa: E402
+
+L = kl.library()
+kem = kyber_amd.KyberHip(3)
+p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+for n in (1, 16, 256, 4096):
+    rng = np.random.default_rng(n)
+    kc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ec = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = kem.keypair(kc)
+    ct, ss = kem.enc(pk, ec)
+    ss2 = np.empty_like(ss)
+    res = {}
+    for name, fn in (("keypair", lambda: L.kyber_batch_keypair(3, 0, n, p(pk), p(sk), p(kc))),
+                     ("enc", lambda: L.kyber_batch_enc(3, 0, n, p(ct), p(ss), p(pk), p(ec))),
+                     ("dec", lambda: L.kyber_batch_dec(3, 0, n, p(ss2), p(ct), p(sk)))):
+        ts = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            assert fn() == 0
+            ts.append(time.perf_counter() - t0)
+        res[name] = np.median(ts) * 1e6
+    assert np.array_equal(ss, ss2)
+    print("n=%5d  keypair %7.1f us  enc %7.1f us  dec %7.1f us" % (n, res["keypair"], res["enc"], res["dec"]))
