@@ -290,45 +290,71 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
 // LDS tiles are half the size.  invntt_tomont and basemul must stay integer in
 // any case: their Montgomery-path representatives in (-q, q) depend on the
 // integer arithmetic itself.)
+//
+// The transform kernels are grid-stride loops: a 32-lane group walks over
+// polynomials pi, pi + stride, ... and issues the 16-byte load of its next
+// polynomial before it transforms the current one.  One launch-sized wave of
+// workgroups doing load -> transform -> store in sequence kept only ~3 MB in
+// flight, a quarter of what HBM latency x bandwidth asks for.
+__device__ __forceinline__ uint4 ld_poly16(const int16_t* base, long pi, int t) {
+  return *reinterpret_cast<const uint4*>(base + pi * 256 + 8 * t);
+}
+__device__ __forceinline__ void st_poly16(int16_t* base, long pi, int t, const int (&c)[8]) { lds_put_contig(base + pi * 256, t, c); }
+
 __global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
-  __shared__ int16_t ztab[128];
+  __shared__ int ztab[128];
   const Grp w = grp();
-  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
-  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
-  int c[8];
-  ld_coef8(r + pi * 256, w.t, c);
   twiddles_to_lds(ztab);
-  lds_put_contig(wk[w.g], w.t, c);
-  KY_GSYNC();
-  ntt_fwd(wk[w.g], ztab, w.t, c);
-  if (live) lds_put_contig(r + pi * 256, w.t, c);
+  const long stride = (long)gridDim.x * 8;
+  long pi = (long)blockIdx.x * 8 + w.g;
+  uint4 nxt = make_uint4(0, 0, 0, 0);
+  if (pi < npoly) nxt = ld_poly16(r, pi, w.t);
+  for (; pi < npoly; pi += stride) {
+    const uint4 cur = nxt;
+    if (pi + stride < npoly) nxt = ld_poly16(r, pi + stride, w.t);
+    int c[8];
+    KY_GSYNC();  // the group's previous transform has left wk
+    *reinterpret_cast<uint4*>(wk[w.g] + 8 * w.t) = cur;
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], ztab, w.t, c);
+    st_poly16(r, pi, w.t, c);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __restrict__ r) {
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ int ztab[128];
   const Grp w = grp();
-  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
-  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
-  __shared__ int16_t ztab[128];
-  int c[8];
-  ld_coef8(r + pi * 256, w.t, c);
   twiddles_to_lds(ztab);
-  ntt_inv(wk[w.g], ztab, w.t, c);
-  stride_to_contig(wk[w.g], w.t, c);
-  if (live) lds_put_contig(r + pi * 256, w.t, c);
+  const long stride = (long)gridDim.x * 8;
+  long pi = (long)blockIdx.x * 8 + w.g;
+  uint4 nxt = make_uint4(0, 0, 0, 0);
+  if (pi < npoly) nxt = ld_poly16(r, pi, w.t);
+  for (; pi < npoly; pi += stride) {
+    const uint4 cur = nxt;
+    if (pi + stride < npoly) nxt = ld_poly16(r, pi + stride, w.t);
+    int c[8];
+    unpack8(cur, c);
+    ntt_inv(wk[w.g], ztab, w.t, c);
+    stride_to_contig(wk[w.g], w.t, c);
+    st_poly16(r, pi, w.t, c);
+    KY_GSYNC();
+  }
 }
 
 // r = a o b (Montgomery domain), no reduction beyond basemul's own.  ref/poly.c:273-280
 __global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
                                                       const int16_t* __restrict__ b) {
+  __shared__ int ztab[128];
   const Grp w = grp();
+  twiddles_to_lds(ztab);
   const long pi = (long)blockIdx.x * 8 + w.g;
   if (pi >= npoly) return;
   int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, x[8], y[8];
   ld_coef8(a + pi * 256, w.t, x);
   ld_coef8(b + pi * 256, w.t, y);
-  basemul_acc(acc, x, y, ZETAS, w.t);
+  basemul_acc(acc, x, y, ztab, w.t);
   lds_put_contig(r + pi * 256, w.t, acc);
 }
 
@@ -337,27 +363,38 @@ __global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __res
 __global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
                                                         const int16_t* __restrict__ b) {
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
+  __shared__ int ztab[128];
   const Grp w = grp();
-  const long pi = min((long)blockIdx.x * 8 + w.g, npoly - 1);
-  const bool live = (long)blockIdx.x * 8 + w.g < npoly;
-  __shared__ int16_t ztab[128];
-  int x[8], y[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  ld_coef8(a + pi * 256, w.t, x);
-  ld_coef8(b + pi * 256, w.t, y);  // both operands in flight before the first transform
   twiddles_to_lds(ztab);
-  lds_put_contig(wk[w.g], w.t, x);
-  KY_GSYNC();
-  ntt_fwd(wk[w.g], ztab, w.t, x);
-  KY_GSYNC();
-  lds_put_contig(wk[w.g], w.t, y);
-  KY_GSYNC();
-  ntt_fwd(wk[w.g], ztab, w.t, y);
-  basemul_acc(acc, x, y, ztab, w.t);
+  const long stride = (long)gridDim.x * 8;
+  long pi = (long)blockIdx.x * 8 + w.g;
+  uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+  if (pi < npoly) {
+    na = ld_poly16(a, pi, w.t);
+    nb = ld_poly16(b, pi, w.t);
+  }
+  for (; pi < npoly; pi += stride) {
+    const uint4 ca = na, cb = nb;
+    if (pi + stride < npoly) {
+      na = ld_poly16(a, pi + stride, w.t);
+      nb = ld_poly16(b, pi + stride, w.t);
+    }
+    int x[8], y[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    KY_GSYNC();
+    *reinterpret_cast<uint4*>(wk[w.g] + 8 * w.t) = ca;
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], ztab, w.t, x);
+    KY_GSYNC();
+    *reinterpret_cast<uint4*>(wk[w.g] + 8 * w.t) = cb;
+    KY_GSYNC();
+    ntt_fwd(wk[w.g], ztab, w.t, y);
+    basemul_acc(acc, x, y, ztab, w.t);
 #pragma unroll
-  for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
-  ntt_inv(wk[w.g], ztab, w.t, acc);
-  stride_to_contig(wk[w.g], w.t, acc);
-  if (live) lds_put_contig(r + pi * 256, w.t, acc);
+    for (int k = 0; k < 8; k++) acc[k] = barrett(acc[k]);
+    ntt_inv(wk[w.g], ztab, w.t, acc);
+    stride_to_contig(wk[w.g], w.t, acc);
+    st_poly16(r, pi, w.t, acc);
+  }
 }
 
 }  // namespace ky

@@ -33,13 +33,18 @@ KY_INSTANTIATE(2)
 KY_INSTANTIATE(3)
 KY_INSTANTIATE(4)
 
-void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_ntt<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r); }
-void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_invntt<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r); }
+// grid-stride transform kernels: 16 workgroups per CU's worth of blocks, each looping over its share
+static inline unsigned stride_grid(size_t npoly) {
+  const unsigned full = nblocks(npoly, 8), cap = 256 * 16;
+  return full < cap ? full : cap;
+}
+void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_ntt<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
+void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_invntt<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
 void launch_poly_basemul(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
   k_poly_basemul<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, a, b);
 }
 void launch_poly_mul_fused(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
-  k_poly_mul_fused<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, a, b);
+  k_poly_mul_fused<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r, a, b);
 }
 
 }  // namespace ky

@@ -30,21 +30,24 @@ namespace ky {
 
 // Twiddles in LDS for the lane-dependent look-ups (a vector load from the
 // constant table costs an L1/L2 round trip per look-up).
-__device__ __forceinline__ void twiddles_to_lds(int16_t* Z) {
-  if (threadIdx.x < 128) Z[threadIdx.x] = ZETAS[threadIdx.x];
+__device__ __forceinline__ void twiddles_to_lds(int* Z) {
+  if (threadIdx.x < 128) Z[threadIdx.x] = tw_pack(ZETAS[threadIdx.x]);
   __syncthreads();
 }
+// compile-time twiddle pair of the fixed early layers
+#define KY_TW(i) tw_pack(ZETAS_HOST[i])
 
 // ---------------------------------------------------------------- butterflies
+// (z is a packed twiddle pair, see fqmul_tw)
 __device__ __forceinline__ void ct_bf(int& a, int& b, int z) {  // ref/ntt.c:89-91
-  int t = fqmul(z, b);
+  int t = fqmul_tw(b, z);
   b = a - t;
   a = a + t;
 }
 __device__ __forceinline__ void gs_bf(int& a, int& b, int z) {  // ref/ntt.c:116-119
   int t = a;
   a = barrett(t + b);
-  b = fqmul(z, b - t);
+  b = fqmul_tw(b - t, z);
 }
 
 // ---------------------------------------------------------------- LDS moves
@@ -88,14 +91,14 @@ __device__ __forceinline__ void lds_get_middle(const int16_t* p, int t, int (&c)
 // in : polynomial in LDS buffer p (natural order), all 32 work-items arrived
 // out: c[] in CONTIG map, Barrett-reduced (= ref/poly.c:244-248 poly_ntt);
 //      p is left holding garbage from the intermediate passes.
-__device__ __forceinline__ void ntt_fwd(int16_t* p, const int16_t* Z, int t, int (&c)[8]) {
+__device__ __forceinline__ void ntt_fwd(int16_t* p, const int* Z, int t, int (&c)[8]) {
   lds_get_stride(p, t, c);
 #pragma unroll
-  for (int m = 0; m < 4; m++) ct_bf(c[m], c[m + 4], ZETAS[1]);
-  ct_bf(c[0], c[2], ZETAS[2]); ct_bf(c[1], c[3], ZETAS[2]);
-  ct_bf(c[4], c[6], ZETAS[3]); ct_bf(c[5], c[7], ZETAS[3]);
-  ct_bf(c[0], c[1], ZETAS[4]); ct_bf(c[2], c[3], ZETAS[5]);
-  ct_bf(c[4], c[5], ZETAS[6]); ct_bf(c[6], c[7], ZETAS[7]);
+  for (int m = 0; m < 4; m++) ct_bf(c[m], c[m + 4], KY_TW(1));
+  ct_bf(c[0], c[2], KY_TW(2)); ct_bf(c[1], c[3], KY_TW(2));
+  ct_bf(c[4], c[6], KY_TW(3)); ct_bf(c[5], c[7], KY_TW(3));
+  ct_bf(c[0], c[1], KY_TW(4)); ct_bf(c[2], c[3], KY_TW(5));
+  ct_bf(c[4], c[5], KY_TW(6)); ct_bf(c[6], c[7], KY_TW(7));
   KY_GSYNC();
   lds_put_stride(p, t, c);
   KY_GSYNC();
@@ -128,7 +131,7 @@ __device__ __forceinline__ void ntt_fwd(int16_t* p, const int16_t* Z, int t, int
 // in : c[] in CONTIG map (NTT domain), p = scratch LDS buffer of the group
 // out: c[] in STRIDE map, multiplied by the Montgomery factor
 //      (= ref/ntt.c:106-126 invntt, "invntt_tomont")
-__device__ __forceinline__ void ntt_inv(int16_t* p, const int16_t* Z, int t, int (&c)[8]) {
+__device__ __forceinline__ void ntt_inv(int16_t* p, const int* Z, int t, int (&c)[8]) {
   {
     int z0 = Z[127 - 2 * t], z1 = Z[126 - 2 * t];
     gs_bf(c[0], c[2], z0); gs_bf(c[1], c[3], z0);
@@ -153,14 +156,14 @@ __device__ __forceinline__ void ntt_inv(int16_t* p, const int16_t* Z, int t, int
   lds_put_middle(p, t, c);
   KY_GSYNC();
   lds_get_stride(p, t, c);
-  gs_bf(c[0], c[1], ZETAS[7]); gs_bf(c[2], c[3], ZETAS[6]);
-  gs_bf(c[4], c[5], ZETAS[5]); gs_bf(c[6], c[7], ZETAS[4]);
-  gs_bf(c[0], c[2], ZETAS[3]); gs_bf(c[1], c[3], ZETAS[3]);
-  gs_bf(c[4], c[6], ZETAS[2]); gs_bf(c[5], c[7], ZETAS[2]);
+  gs_bf(c[0], c[1], KY_TW(7)); gs_bf(c[2], c[3], KY_TW(6));
+  gs_bf(c[4], c[5], KY_TW(5)); gs_bf(c[6], c[7], KY_TW(4));
+  gs_bf(c[0], c[2], KY_TW(3)); gs_bf(c[1], c[3], KY_TW(3));
+  gs_bf(c[4], c[6], KY_TW(2)); gs_bf(c[5], c[7], KY_TW(2));
 #pragma unroll
-  for (int m = 0; m < 4; m++) gs_bf(c[m], c[m + 4], ZETAS[1]);
+  for (int m = 0; m < 4; m++) gs_bf(c[m], c[m + 4], KY_TW(1));
 #pragma unroll
-  for (int m = 0; m < 8; m++) c[m] = fqmul(c[m], 1441);  // 2^32/128 mod q
+  for (int m = 0; m < 8; m++) c[m] = fqmul_tw(c[m], tw_pack(1441));  // 2^32/128 mod q
 }
 
 // STRIDE -> CONTIG through the group's LDS buffer
@@ -175,14 +178,14 @@ __device__ __forceinline__ void stride_to_contig(int16_t* p, int t, int (&c)[8])
 // acc[] += a[] o b[] for the work-item's 8 CONTIG coefficients: two products in
 // Z_q[X]/(X^2 - zeta) and two in Z_q[X]/(X^2 + zeta).  ref/ntt.c:139-146 as
 // driven by ref/poly.c:273-280; summation as ref/polyvec.c:194-198.
-__device__ __forceinline__ void basemul_acc(int (&acc)[8], const int (&a)[8], const int (&b)[8], const int16_t* Z, int t) {
+__device__ __forceinline__ void basemul_acc(int (&acc)[8], const int (&a)[8], const int (&b)[8], const int* Z, int t) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
-    int z = Z[64 + 2 * t + g];
+    const int z = Z[64 + 2 * t + g];  // twiddle pair
     const int o = 4 * g;
-    acc[o + 0] += fqmul(fqmul(a[o + 1], b[o + 1]), z) + fqmul(a[o + 0], b[o + 0]);
+    acc[o + 0] += fqmul_tw(fqmul(a[o + 1], b[o + 1]), z) + fqmul(a[o + 0], b[o + 0]);
     acc[o + 1] += fqmul(a[o + 0], b[o + 1]) + fqmul(a[o + 1], b[o + 0]);
-    acc[o + 2] += fqmul(fqmul(a[o + 3], b[o + 3]), -z) + fqmul(a[o + 2], b[o + 2]);
+    acc[o + 2] += fqmul_tw(-fqmul(a[o + 3], b[o + 3]), z) + fqmul(a[o + 2], b[o + 2]);  // ref/ntt.c:145: times -zeta
     acc[o + 3] += fqmul(a[o + 2], b[o + 3]) + fqmul(a[o + 3], b[o + 2]);
   }
 }
