@@ -60,38 +60,74 @@ __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restri
   const int inst0 = blockIdx.x * G_INST;
   f_twiddles_to_lds(ztab);
 
-  for (int q = w.g; q < G_INST * 2 * K; q += 8) {
-    const int li = q / (2 * K), v = q % (2 * K);
-    const int gi = min(inst0 + li, n - 1);
-    int c[8];
-    float f[8];
-    cbd_contig<P::ETA1>(prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE, w.t, c);
-    i2f8(c, f);
-    f_ntt_fwd(wk[w.g], ztab, w.t, f);
-    f_put_i16(se[li][v], w.t, f);
-    if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
-      f2canon8(f, c);
-      st_bytes12(sk + (size_t)gi * P::SKB + 384 * v, w.t, c);
+  // global operands are fetched one iteration ahead, as in k_enc_arith
+  {
+    auto fetch = [&](int q, uint32_t (&r)[3]) {
+      const int li = q / (2 * K), v = q % (2 * K);
+      const int gi = min(inst0 + li, n - 1);
+      const uint8_t* b = prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE;
+      if constexpr (P::ETA1 == 2) {
+        r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+      } else {
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
+        r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+      }
+    };
+    uint32_t nxt[3] = {0, 0, 0};
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * 2 * K; q += 8) {
+      const int li = q / (2 * K), v = q % (2 * K);
+      const int gi = min(inst0 + li, n - 1);
+      const uint32_t cur[3] = {nxt[0], nxt[1], nxt[2]};
+      if (q + 8 < G_INST * 2 * K) fetch(q + 8, nxt);
+      int c[8];
+      float f[8];
+      if constexpr (P::ETA1 == 2) cbd2_word(cur[0], c);
+      else cbd3_words(cur[0] | (cur[1] & 0xFFu) << 16, (cur[1] >> 8) | cur[2] << 8, c);
+      i2f8(c, f);
+      f_ntt_fwd(wk[w.g], ztab, w.t, f);
+      f_put_i16(se[li][v], w.t, f);
+      if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
+        f2canon8(f, c);
+        st_bytes12(sk + (size_t)gi * P::SKB + 384 * v, w.t, c);
+      }
     }
   }
   __syncthreads();
-  for (int q = w.g; q < G_INST * K; q += 8) {
-    const int li = q / K, i = q % K;
-    const int gi = min(inst0 + li, n - 1);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+  {
+    auto fetch = [&](int q, uint4 (&a)[K]) {
+      const int li = q / K, i = q % K;
+      const int gi = min(inst0 + li, n - 1);
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      ld_coef8f(mat + ((size_t)gi * P::NMAT + i * K + j) * 256, w.t, a);
-      f_get_i16(se[li][j], w.t, b);
-      f_basemul_acc(acc, a, b, ztab, w.t);
-    }
-    f_get_i16(se[li][K + i], w.t, b);
-    int c[8];
+      for (int j = 0; j < K; j++)
+        a[j] = *reinterpret_cast<const uint4*>(mat + ((size_t)gi * P::NMAT + i * K + j) * 256 + 8 * w.t);
+    };
+    uint4 nxt[K];
+    fetch(w.g, nxt);
+    for (int q = w.g; q < G_INST * K; q += 8) {
+      const int li = q / K, i = q % K;
+      const int gi = min(inst0 + li, n - 1);
+      uint4 cur[K];
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + b[k]));  // + e^   ref/indcpa.c:234-235
-    if (inst0 + li < n) {
-      st_bytes12(pk + (size_t)gi * P::PKB + 384 * i, w.t, c);
-      st_bytes12(sk + (size_t)gi * P::SKB + P::PVB + 384 * i, w.t, c);
+      for (int j = 0; j < K; j++) cur[j] = nxt[j];
+      if (q + 8 < G_INST * K) fetch(q + 8, nxt);
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        int ai[8];
+        unpack8(cur[j], ai);
+        i2f8(ai, a);
+        f_get_i16(se[li][j], w.t, b);
+        f_basemul_acc(acc, a, b, ztab, w.t);
+      }
+      f_get_i16(se[li][K + i], w.t, b);
+      int c[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + b[k]));  // + e^   ref/indcpa.c:234-235
+      if (inst0 + li < n) {
+        st_bytes12(pk + (size_t)gi * P::PKB + 384 * i, w.t, c);
+        st_bytes12(sk + (size_t)gi * P::SKB + P::PVB + 384 * i, w.t, c);
+      }
     }
   }
   // rho -> pk tail and its copy inside sk
