@@ -317,36 +317,27 @@ __device__ __forceinline__ int drain_tile2(uint32_t* tile, int lane, long job0, 
 }
 
 // Lane-private drain: every lane copies its own staging row to its own
-// polynomial with 16-byte stores (rows are private, so no cross-lane traffic,
-// no readlanes and one store instruction moves up to 1 KB for the wavefront).
-// Up to three dwords past the lane's count may be written; they lie inside the
-// same polynomial and are overwritten by the next piece (or by the tail kernel),
-// and a store that would cross the end of the polynomial is done dword by dword.
-struct __attribute__((packed, aligned(4))) dword4 {
-  uint32_t x, y, z, w;
-};
+// polynomial (rows are private, so no cross-lane traffic and no readlanes).
+// Up to three single dwords bring the destination to a 16-byte boundary, the
+// rest leaves as aligned 16-byte stores read from the row at the matching
+// offset.  An aligned store may carry up to three dwords past the lane's
+// count; they lie inside the same polynomial (whose end is 16-byte aligned) and
+// are overwritten by the next piece or by the tail kernel.
 template <int SDW>
 __device__ __forceinline__ int drain_private(uint32_t* row, long job, int c0, int c1, uint32_t* mat32) {
   const int d0 = c0 >> 1;
   const int nd = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0 : 0;
-  uint32_t v[(SDW + 3) & ~3];
-#pragma unroll
-  for (int u = 0; u < SDW; u++) v[u] = row[u];
-#pragma unroll
-  for (int u = SDW; u < ((SDW + 3) & ~3); u++) v[u] = 0;
+  const int head = min((4 - (d0 & 3)) & 3, nd);
   uint32_t* dst = mat32 + job * 128 + d0;
 #pragma unroll
-  for (int q = 0; q < (SDW + 3) / 4; q++) {
-    if (4 * q < nd) {
-      if (d0 + 4 * q + 3 < 128) {
-        *reinterpret_cast<dword4*>(dst + 4 * q) = dword4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      } else {
+  for (int r = 0; r < 3; r++)
+    if (r < head) dst[r] = row[r];
+  const uint32_t* src = row + head;
+  uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
+  const int body = nd - head;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-          if (d0 + 4 * q + r < 128) dst[4 * q + r] = v[4 * q + r];
-      }
-    }
-  }
+  for (int q = 0; q < (SDW + 3) / 4; q++)
+    if (4 * q < body) dst4[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
   if (c0 < 256 && (c1 & 1)) {
     uint16_t* h = reinterpret_cast<uint16_t*>(row);
     h[0] = h[(c0 & 1) + (c1 - c0) - 1];
@@ -386,7 +377,7 @@ template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: 
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                        int transposed, int16_t* __restrict__ mat,
                                                        uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  __shared__ uint32_t stage[4][64 * MAT_STAGE_DW];
+  __shared__ uint32_t stage[4 * 64 * MAT_STAGE_DW + 8];  // + 8: the drain reads whole 16-byte groups from a row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long job0 = (long)blockIdx.x * 256 + wave * 64;  // first job of this wavefront
   const long job = job0 + lane;
@@ -404,9 +395,8 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   A[4].lo = x | y << 8 | 0x1F0000u;  // rho || x || y || pad    ref/symmetric-shake.c:25-29
   A[20].hi = 0x80000000u;
 
-  uint32_t* row = stage[wave] + lane * MAT_STAGE_DW;
+  uint32_t* row = stage + (wave * 64 + lane) * MAT_STAGE_DW;
   const uint32_t row_addr = lds_addr(row);
-  uint32_t* tile = stage[wave];
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
   int ctr = valid ? 0 : 256;
   int blk = 0;
