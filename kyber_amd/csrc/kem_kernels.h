@@ -210,12 +210,12 @@ __global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_et
 // refill-and-carry is the same as this continuous stream parse because
 // 168 % 3 == 0).
 //
-// Per block each lane appends its accepted values to a private row of an LDS
-// staging tile ("always store, advance only on accept": no divergent branch),
-// then the wavefront drains the tile row by row so that every global store is
-// a contiguous run of one polynomial.  Lanes that still miss coefficients after
-// three blocks (P ~ 0.8 % each) keep the whole wavefront squeezing.
-constexpr int STAGE_DW = 57;  // whole-block row: 1 carry slot + 112 candidates + 1 spill (drain_tile)
+// Each lane appends its accepted values to a private row of an LDS staging
+// tile ("always store, advance only on accept": no divergent branch) and then
+// copies the row to its polynomial with 16-byte stores (drain_private).  Entries
+// that still miss coefficients after three blocks (P ~ 0.9 % each) are handed
+// to k_sample_matrix_tail through a queue instead of keeping their wavefront
+// squeezing.
 
 template <int BITOFF, int N>
 __device__ __forceinline__ uint32_t field12(const uint32_t (&H)[N]) {
@@ -252,68 +252,6 @@ __device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& wa
     parse_group<G0, N>(H, waddr);
     parse_range<G0 + 1, G1, N>(H, waddr);
   }
-}
-
-// Drain one parsed chunk of a wavefront's staging tile (rows of SDW dwords, one
-// per lane) into the polynomials mat32[(job0 + p) * 128 ...]: lane p's
-// polynomial gets dwords [c0>>1, (min(c1,256)+1)>>1) of its row.  Eight rows per
-// step, all LDS reads issued before the first store, so the LDS latency is paid
-// once per step instead of once per row.  Then carries an unpaired last
-// coefficient to slot 0 of the row for the next chunk.  Returns the new count.
-template <int SDW>
-__device__ __forceinline__ int drain_tile(uint32_t* tile, int lane, long job0, int c0, int c1, uint32_t* mat32) {
-  const int d0v = c0 >> 1;
-  const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
-#pragma unroll 1
-  for (int p0 = 0; p0 < 64; p0 += 8) {
-    uint32_t v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = tile[(p0 + u) * SDW + lane];
-#pragma unroll
-    for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int d0 = __builtin_amdgcn_readlane(d0v, p0 + u), nd = __builtin_amdgcn_readlane(ndv, p0 + u);
-      if (lane < nd) mat32[(job0 + p0 + u) * 128 + d0 + lane] = v[u];
-    }
-  }
-  if (c0 < 256 && (c1 & 1)) {
-    uint16_t* h = reinterpret_cast<uint16_t*>(tile + lane * SDW);
-    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
-  }
-  return c0 < 256 ? c1 : c0;
-}
-
-// Same for a tile whose rows hold at most 32 dwords: each half of the wavefront
-// drains its own row, so one store instruction covers two polynomials.
-template <int SDW>
-__device__ __forceinline__ int drain_tile2(uint32_t* tile, int lane, long job0, int c0, int c1, uint32_t* mat32) {
-  static_assert(SDW <= 32, "a row must fit half a wavefront");
-  const int d0v = c0 >> 1;
-  const int ndv = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0v : 0;
-  const uint32_t meta = (uint32_t)d0v | (uint32_t)ndv << 16;
-  const int l = lane & 31, hi = lane & 32;  // rows p (lanes 0..31) and p + 32 (lanes 32..63)
-  const uint32_t* src = tile + hi * SDW + l;
-  uint32_t* dst = mat32 + (job0 + hi) * 128 + l;
-#pragma unroll 1
-  for (int p0 = 0; p0 < 32; p0 += 8) {
-    uint32_t v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = src[(p0 + u) * SDW];
-#pragma unroll
-    for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));  // keep the reads ahead of the branches
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t mlo = __builtin_amdgcn_readlane(meta, p0 + u), mhi = __builtin_amdgcn_readlane(meta, p0 + u + 32);
-      const uint32_t m = hi ? mhi : mlo;
-      if (l < (int)(m >> 16)) dst[(p0 + u) * 128 + (m & 0xFFFFu)] = v[u];
-    }
-  }
-  if (c0 < 256 && (c1 & 1)) {
-    uint16_t* h = reinterpret_cast<uint16_t*>(tile + lane * SDW);
-    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
-  }
-  return c0 < 256 ? c1 : c0;
 }
 
 // Lane-private drain: every lane copies its own staging row to its own

@@ -186,7 +186,7 @@ template <class P>
 __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                          int transposed, int16_t* __restrict__ mat) {
   __shared__ uint32_t tab[AES_TABLE_DW];
-  __shared__ uint32_t stage[4][64 * STAGE90_DW];
+  __shared__ uint32_t stage[4 * 64 * STAGE90_DW + 8];  // + 8: drain_private reads whole 16-byte groups
   aes_table_init(tab);
   const AesLds L = aes_lds(tab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,8 +203,8 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
   ld32B(rho + (size_t)inst * rho_stride, key);
   aes256_expand(L, key, rk);
 
-  uint32_t* tile = stage[wave];
-  const uint32_t row_addr = lds_addr(tile + lane * STAGE90_DW);
+  uint32_t* row = stage + (wave * 64 + lane) * STAGE90_DW;
+  const uint32_t row_addr = lds_addr(row);
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
   int ctr = valid ? 0 : 256;
   uint32_t blk = 0;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
     uint32_t waddr = w0;
     parse_range<0, 32, 24>(H, waddr);
     const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
-    ctr = drain_tile<STAGE90_DW>(tile, lane, job0, c0, c1, out32);
+    ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
   }
 }
 
