@@ -178,9 +178,11 @@ __global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_
 // byte stream, three bytes at a time (ref/indcpa.c:124-145,164-192 with
 // ref/symmetric-aes.c:7-13).  The reference squeezes 512 bytes, then 64 at a
 // time carrying buflen % 3 bytes over; that is a continuous parse of the
-// keystream, reproduced here 96 bytes (six AES blocks, 32 three-byte groups)
+// keystream, reproduced here 48 bytes (three AES blocks, 16 three-byte groups)
 // per step so that no group straddles a step.
-constexpr int STAGE90_DW = 33;  // 1 carry slot + 64 candidates + 1 spill, in dwords
+constexpr int XOF90_BLOCKS = 3;                                 // AES blocks per step
+constexpr int XOF90_GROUPS = 16 * XOF90_BLOCKS / 3;             // 3-byte groups per step
+constexpr int STAGE90_DW = (2 * XOF90_GROUPS + 2) / 2;          // 1 carry slot + candidates + 1 spill, in dwords
 
 template <class P>
 __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
@@ -209,20 +211,20 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
   int ctr = valid ? 0 : 256;
   uint32_t blk = 0;
   while (__any(ctr < 256)) {
-    uint32_t H[24];
+    uint32_t H[4 * XOF90_BLOCKS];
 #pragma unroll 1
-    for (int b = 0; b < 6; b++) {
+    for (int b = 0; b < XOF90_BLOCKS; b++) {
       uint32_t o[4];
       aes256ctr_block(L, rk, x | y << 8, blk + b, o);
       // H[4b..4b+3] = o, with a compile-time destination (b is a run-time loop index)
 #pragma unroll
-      for (int bb = 0; bb < 6; bb++)
+      for (int bb = 0; bb < XOF90_BLOCKS; bb++)
         if (bb == b) { H[4 * bb] = o[0]; H[4 * bb + 1] = o[1]; H[4 * bb + 2] = o[2]; H[4 * bb + 3] = o[3]; }
     }
-    blk += 6;
+    blk += XOF90_BLOCKS;
     const uint32_t w0 = row_addr + 2u * (ctr & 1);
     uint32_t waddr = w0;
-    parse_range<0, 32, 24>(H, waddr);
+    parse_range<0, XOF90_GROUPS, 4 * XOF90_BLOCKS>(H, waddr);
     const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
     ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
   }
