@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_kdf_parts(int n, const uint8_t* __restr
 template <class P>
 __global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
                                                int seed_off, uint8_t* __restrict__ prf) {
-  __shared__ uint32_t tab[AES_TABLE_DW];
+  KY_AES_TABLE(tab);
   aes_table_init(tab);
   const AesLds L = aes_lds(tab);
   long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -187,7 +187,7 @@ constexpr int STAGE90_DW = (2 * XOF90_GROUPS + 2) / 2;          // 1 carry slot 
 template <class P>
 __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                          int transposed, int16_t* __restrict__ mat) {
-  __shared__ uint32_t tab[AES_TABLE_DW];
+  KY_AES_TABLE(tab);
   __shared__ uint32_t stage[4 * 64 * STAGE90_DW + 8];  // + 8: drain_private reads whole 16-byte groups
   aes_table_init(tab);
   const AesLds L = aes_lds(tab);
