@@ -166,7 +166,8 @@ void *kyber_hip_host_alloc(size_t bytes);
 void kyber_hip_host_free(void *p);
 
 /* ---- housekeeping ---- */
-/* instances processed per internal pass (workspace sizing); 0 restores the default */
+/* instances processed per internal pass (workspace sizing); 0 restores the default
+ * (2^19), more than 2^24 is refused with KYBER_HIP_EINVAL */
 int kyber_hip_set_chunk(size_t instances);
 /* Tuning/test aid (no counterpart in the reference): upper bound on the records
  * of the matrix sampler's tail queue per pass.  Entries that do not fit are

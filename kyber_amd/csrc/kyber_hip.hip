@@ -880,6 +880,7 @@ void kyber_hip_host_free(void* p) {
 
 int kyber_hip_set_chunk(size_t instances) {
   std::lock_guard<std::mutex> lk(g_mu);
+  if (instances > ((size_t)1 << 24)) return KYBER_HIP_EINVAL;  // chunk * K^2 matrix entries are indexed with int
   g_chunk = instances ? instances : DEFAULT_CHUNK;
   return 0;
 }

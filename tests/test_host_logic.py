@@ -105,3 +105,44 @@ def test_float_compress_formula_is_exact():
         # distance to the nearest rounding boundary really exceeds the constant's error
         frac = (u.astype(np.float64) * (1 << d) / q) % 1.0
         assert np.min(np.abs(frac[u != 0] - 0.5)) > 1.49e-4
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """shared-key, key-exchange and tuning entry points: argument checks come
+    before any HIP call (ref/kex.h and the batch API have no error returns;
+    the negative codes are this library's)."""
+    lib = kyber_amd.library()
+    from kyber_amd import kex as kx
+    kx._bind(lib)
+    buf = (ctypes.c_uint8 * 8192)()
+    assert lib.kyber_batch_enc_shared_pk(9, 0, 1, buf, buf, buf, buf) == -1
+    assert lib.kyber_batch_dec_shared_sk(3, 0, 1, None, buf, buf) == -1
+    assert lib.kyber_batch_enc_shared_pk(3, 1, 0, buf, buf, buf, None) == 0
+    assert lib.kyber_batch_kex_uake_initA(3, 0, 1, buf, buf, buf, buf, buf, 2) == -1      # unknown flag
+    assert lib.kyber_batch_kex_ake_sharedB(3, 0, 1, buf, buf, buf, buf, None, buf, 0) == -1  # NULL pka
+    assert lib.kyber_batch_kex_ake_sharedA(5, 0, 1, buf, buf, buf, buf, buf) == -1
+    assert lib.kyber_batch_kex_uake_sharedA(2, 1, 0, buf, buf, buf, buf) == 0
+    assert lib.kyber_hip_set_chunk((1 << 24) + 1) == -1
+    assert lib.kyber_hip_set_chunk(0) == 0
+    assert lib.kyber_hip_set_tail_capacity((1 << 64) - 1) == 0
+
+
+def test_16bit_montgomery_forms_match_reference_reduce(oracle):
+    """field.h builds Montgomery products from v_mul_lo_u16 / v_mad_i32_i16:
+    t = int16(low16(b) * low16(w_hi)); r = (z*b - t*q) >> 16 with the twiddle
+    pair w = z | (z * q^-1 mod 2^16) << 16.  Same integers as
+    montgomery_reduce(z*b) of ref/reduce.c:16-23 for every int16 b and every zeta."""
+    q, qinv = 3329, 62209
+    zetas = np.ctypeslib.as_array(oracle.lib.ko_zetas(), (128,)).astype(np.int64)
+    b = np.arange(-32768, 32768, dtype=np.int64)
+    for z in list(zetas[::9]) + [1441, -1044]:
+        zq = (z * qinv) & 0xFFFF
+        m = ((b & 0xFFFF) * zq) & 0xFFFF
+        m = np.where(m >= 32768, m - 65536, m)          # the mad reads it as int16
+        got = (z * b - m * q) >> 16
+        a = z * b
+        t = (a * qinv) & 0xFFFF
+        t = np.where(t >= 32768, t - 65536, t)          # (int16_t)a * QINV  ref/reduce.c:20
+        want = (a - t * q) >> 16
+        assert np.array_equal(got, want)
+        assert np.all((got * 65536 - a) % q == 0) and np.all(np.abs(got) < q)
