@@ -41,6 +41,9 @@ constexpr size_t DEFAULT_CHUNK = 1u << 19;  // 3 GB of workspace for Kyber768; k
 struct Workspace {
   void* base = nullptr;
   size_t bytes = 0;
+  hipEvent_t idle = nullptr;        // recorded after the last kernel that uses the workspace
+  hipStream_t last = nullptr;       // ... on this stream
+  bool used = false;
 };
 Workspace g_ws[MAX_DEV];
 size_t g_chunk = DEFAULT_CHUNK;
@@ -65,6 +68,32 @@ int ws_reserve(size_t bytes, uint8_t** out) {
   *out = static_cast<uint8_t*>(w.base);
   return 0;
 }
+
+// The workspace is one per device, so the GPU work of two pipeline calls must not
+// overlap even when they are queued on different streams (or from different
+// host threads): a call first makes its stream wait for the event the previous
+// call recorded behind its last kernel.  Calls on one stream cost nothing extra.
+struct WsUse {
+  hipStream_t st;
+  Workspace* w = nullptr;
+  explicit WsUse(hipStream_t s) : st(s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return;
+    w = &g_ws[dev];
+    if (!w->idle && hipEventCreateWithFlags(&w->idle, hipEventDisableTiming) != hipSuccess) {
+      w->idle = nullptr;
+      w = nullptr;
+      return;
+    }
+    if (w->used && w->last != st) (void)hipStreamWaitEvent(st, w->idle, 0);
+  }
+  ~WsUse() {
+    if (!w) return;
+    (void)hipEventRecord(w->idle, st);
+    w->last = st;
+    w->used = true;
+  }
+};
 
 template <class P>
 struct Layout {
@@ -166,6 +195,7 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
+  WsUse use(st);
   const size_t chunk = n < g_chunk ? n : g_chunk;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
@@ -198,6 +228,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
 template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
+  WsUse use(st);
   const size_t chunk = n < g_chunk ? n : g_chunk;
   const bool shared = pk_stride == 0;
   Layout<P> L;
@@ -241,6 +272,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 template <class P, bool N90>
 int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
+  WsUse use(st);
   const size_t chunk = n < g_chunk ? n : g_chunk;
   const bool shared = sk_stride == 0;
   Layout<P> L;
@@ -900,6 +932,7 @@ int kyber_hip_release(void) {
   if (g_ws[dev].base) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(g_ws[dev].base));
+    if (g_ws[dev].idle) (void)hipEventDestroy(g_ws[dev].idle);
     g_ws[dev] = Workspace{};
   }
   if (HostCtx* c = g_host[dev]) {

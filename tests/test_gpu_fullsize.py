@@ -94,3 +94,31 @@ def test_host_pipeline_multi_pass_pinned_and_pageable(oracle):
     assert np.array_equal(kem.dec_shared_sk(sct, sk[5]), sss)
     assert np.array_equal(sct[idx], oracle.enc(k, np.tile(pk[5], (len(idx), 1)), ec[idx])[0])
     del ppk, pec
+
+
+def test_calls_on_different_streams_do_not_race_on_the_workspace():
+    """Two encapsulation batches queued on two streams without any host
+    synchronisation in between: the library orders them on the device (one
+    workspace per device), so both results equal their single-stream runs."""
+    kem = kyber_amd.KyberHip(3)
+    dev = torch.device("cuda", 0)
+    n = 1 << 16
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device=dev, generator=g)
+    e1 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    e2 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    pk, sk = kem.keypair_dev(kc)
+    want1, want_s1 = kem.enc_dev(pk, e1)
+    want2, want_s2 = kem.enc_dev(pk, e2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            ct1, ss1 = kem.enc_dev(pk, e1)
+        with torch.cuda.stream(s2):
+            ct2, ss2 = kem.enc_dev(pk, e2)
+            back = kem.dec_dev(ct2, sk)
+        torch.cuda.synchronize()
+        assert torch.equal(ct1, want1) and torch.equal(ss1, want_s1)
+        assert torch.equal(ct2, want2) and torch.equal(ss2, want_s2) and torch.equal(back, want_s2)
