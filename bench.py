@@ -66,9 +66,12 @@ def pmc_traffic(kernel, k, chunk):
     return None, None
 
 
-def cpu_baseline(budget_s=20.0):
-    """Time the reference's own code (oracle/_ref, built from /root/reference's
-    ref/ and avx2/ sources) on the host cores; falls back to the oracle port."""
+def cpu_baseline(budget_s=20.0, sample=None):
+    """The CPU leg (the only place this program touches oracle/): time the
+    reference's own code (oracle/_ref, built from /root/reference's ref/ and
+    avx2/ sources; falls back to the oracle port) on the host cores, and check
+    a strided sample of what the GPU just produced against the same code.
+    sample = dict(kc, ec, pk, sk, ct, ss) of numpy arrays, or None."""
     import numpy as np
     import oracle_lib
 
@@ -90,6 +93,15 @@ def cpu_baseline(budget_s=20.0):
             def enc(self, pk, c): return o.enc(K, pk, c, N90)
             def dec(self, ct, sk): return o.dec(K, ct, sk, N90)
         lib = _Port()
+
+    sample_ok = None
+    if sample is not None:
+        spk, ssk = lib.keypair(sample["kc"])
+        sct, sss = lib.enc(spk, sample["ec"])
+        sample_ok = bool(np.array_equal(spk, sample["pk"]) and np.array_equal(ssk, sample["sk"])
+                         and np.array_equal(sct, sample["ct"]) and np.array_equal(sss, sample["ss"])
+                         and np.array_equal(lib.dec(sct, ssk), sample["ss"]))
+        assert sample_ok, "strided sample of the GPU results differs from the %s code" % kind
 
     # calibrate on one core
     n0 = 512
@@ -121,6 +133,7 @@ def cpu_baseline(budget_s=20.0):
         "value": threads * per_thread / dt, "unit": "encaps+decaps/s", "cores": threads, "kind": kind,
         "impl": impl, "one_core": one_core,
         "sample": "enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt),
+        "gpu_sample_bit_exact": sample_ok,
     }
 
 
@@ -245,21 +258,13 @@ def main():
         dt = float(t.item())
 
     # correctness of what was just timed: every decapsulated secret equals the
-    # encapsulated one, and a strided sample is bit-exact against the oracle
+    # encapsulated one; a strided sample goes to the CPU leg for a bit-exact check
     assert torch.equal(ssa, ssb), "decaps != encaps shared secret"
+    idx = torch.arange(0, n, 4096, device=dev)
+    kidx = torch.zeros_like(idx) if args.shared_key else idx
+    sample = {"kc": kcoins[kidx].cpu().numpy(), "ec": ecoins[idx].cpu().numpy(), "pk": pk[kidx].cpu().numpy(),
+              "sk": sk[kidx].cpu().numpy(), "ct": ct[idx].cpu().numpy(), "ss": ssa[idx].cpu().numpy()}
     parity = None
-    try:
-        import oracle_lib
-        o = oracle_lib.load_oracle()
-        idx = torch.arange(0, n, 4096, device=dev)
-        kidx = torch.zeros_like(idx) if args.shared_key else idx
-        opk, osk = o.keypair(K, kcoins[kidx].cpu().numpy(), N90)
-        oct_, oss = o.enc(K, opk, ecoins[idx].cpu().numpy(), N90)
-        parity = bool(np.array_equal(pk[kidx].cpu().numpy(), opk) and np.array_equal(sk[kidx].cpu().numpy(), osk)
-                      and np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssa[idx].cpu().numpy(), oss))
-        assert parity, "strided sample differs from the oracle"
-    except (OSError, ImportError):
-        parity = None
 
     # per-kernel durations: a separate, untimed pass with HIP events on the launch stream
     roof = None
@@ -307,7 +312,7 @@ def main():
             "config": {"workload": "%s batched encaps+decaps%s, %d instances per GPU per step, device-resident"
                        % (set_name, " with one shared key pair" if args.shared_key else "", n),
                        "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective"},
-            "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_oracle": parity},
+            "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_cpu_reference": parity},
             "pipeline": {"valu_frac": value / world * ENCDEC_PERMS * KECCAK_LANE_OPS * 1e-12 / VALU_PEAK_TLOPS,
                          "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS},
             "roofline": roof, "kernels": kernels,
@@ -318,7 +323,10 @@ def main():
                 roof.update({"achieved": None, "frac": None})
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(sample=sample)
+                out["parity"]["strided_sample_vs_cpu_reference"] = out["cpu_baseline"]["gpu_sample_bit_exact"]
+            except AssertionError:
+                raise
             except Exception as e:  # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
