@@ -41,7 +41,7 @@ def test_drbg_coins_match():
 
 
 def test_usage_errors():
-    for exe in ("test_vectors_hip", "kat_hip"):
+    for exe in ("test_vectors_hip", "kat_hip", "test_kyber_hip", "test_kex_hip"):
         r = subprocess.run([os.path.join(H, exe), "999"], capture_output=True)
         assert r.returncode == 2 and b"usage" in r.stderr
 
@@ -71,3 +71,18 @@ def test_kat_rsp_format():
     ct, ss = kem.enc(pk, ec)
     for i in range(3):
         assert recs[i] + "\n" == vectors.kat_record(i, coins[i][0], pk[i], sk[i], ct[i], ss[i]).decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["512", "768", "1024", "512-90s", "768-90s", "1024-90s"])
+def test_reference_functional_tests_on_gpu(name):
+    """ref/test_kyber.c (1000 rounds of keys / invalid sk / invalid ciphertext)
+    and ref/test_kex.c relinked against the library: same pass criteria, same
+    size lines on stdout (ref/test_kyber.c:107-109, ref/test_kex.c:60-63)."""
+    k = {"512": 2, "768": 3, "1024": 4}[name.split("-")[0]]
+    pkb, skb, ctb = 384 * k + 32, 768 * k + 96, 32 * ((11 if k == 4 else 10) * k + (5 if k == 4 else 4))
+    out = _run(os.path.join(H, "test_kyber_hip"), name).decode()
+    assert out == "CRYPTO_SECRETKEYBYTES:  %d\nCRYPTO_PUBLICKEYBYTES:  %d\nCRYPTO_CIPHERTEXTBYTES: %d\n" % (skb, pkb, ctb)
+    out = _run(os.path.join(H, "test_kex_hip"), name).decode()
+    assert out == ("KEX_UAKE_SENDABYTES: %d\nKEX_UAKE_SENDBBYTES: %d\nKEX_AKE_SENDABYTES: %d\nKEX_AKE_SENDBBYTES: %d\n"
+                   % (pkb + ctb, ctb, pkb + ctb, 2 * ctb))
