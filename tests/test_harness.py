@@ -41,7 +41,7 @@ def test_drbg_coins_match():
 
 
 def test_usage_errors():
-    for exe in ("test_vectors_hip", "kat_hip", "test_kyber_hip", "test_kex_hip"):
+    for exe in ("test_vectors_hip", "kat_hip", "test_kyber_hip", "test_kex_hip", "test_speed_hip"):
         r = subprocess.run([os.path.join(H, exe), "999"], capture_output=True)
         assert r.returncode == 2 and b"usage" in r.stderr
 
