@@ -117,11 +117,40 @@ __device__ __forceinline__ void aes256_encrypt(const AesLds& L, const uint32_t (
   out[3] = aes_col_last(L, s3, s0, s1, s2, rk[59]);
 }
 
-// keystream block number ctr for nonce word n0 (nonce bytes 4..11 are zero in
-// every use the KEM makes: ref/symmetric-aes.c:7-20)
-__device__ __forceinline__ void aes256ctr_block(const AesLds& L, const uint32_t (&rk)[60], uint32_t n0, uint32_t ctr, uint32_t (&out)[4]) {
-  const uint32_t in[4] = {n0, 0u, 0u, bswap32(ctr)};
-  aes256_encrypt(L, rk, in, out);
+// Counter mode with the KEM's nonces (bytes 4..11 zero: ref/symmetric-aes.c:7-20):
+// the input block is (n0, 0, 0, bswap(ctr)), so after the first AddRoundKey three
+// of the four state words are the same for every block of a stream.  Round 1
+// has exactly one look-up per output column that depends on the counter word;
+// the other twelve are folded once per stream into p[] (with the round key).
+struct AesCtr {
+  uint32_t p[4];
+};
+__device__ __forceinline__ AesCtr aes256ctr_init(const AesLds& L, const uint32_t (&rk)[60], uint32_t n0) {
+  const uint32_t s0 = n0 ^ rk[0], s1 = rk[1], s2 = rk[2];
+  AesCtr c;
+  c.p[0] = bitop3<0x96>(L.look<0>(s0), rotl32(L.look<1>(s1), 8), rotl32(L.look<2>(s2), 16)) ^ rk[4];   // + rotl24 T0[s3.b3]
+  c.p[1] = bitop3<0x96>(L.look<0>(s1), rotl32(L.look<1>(s2), 8), rotl32(L.look<3>(s0), 24)) ^ rk[5];   // + rotl16 T0[s3.b2]
+  c.p[2] = bitop3<0x96>(L.look<0>(s2), rotl32(L.look<2>(s0), 16), rotl32(L.look<3>(s1), 24)) ^ rk[6];  // + rotl8  T0[s3.b1]
+  c.p[3] = bitop3<0x96>(rotl32(L.look<1>(s0), 8), rotl32(L.look<2>(s1), 16), rotl32(L.look<3>(s2), 24)) ^ rk[7];  // + T0[s3.b0]
+  return c;
+}
+// keystream block number ctr
+__device__ __forceinline__ void aes256ctr_block(const AesLds& L, const uint32_t (&rk)[60], const AesCtr& c, uint32_t ctr, uint32_t (&out)[4]) {
+  const uint32_t v = bswap32(ctr) ^ rk[3];
+  uint32_t s0 = c.p[0] ^ rotl32(L.look<3>(v), 24), s1 = c.p[1] ^ rotl32(L.look<2>(v), 16), s2 = c.p[2] ^ rotl32(L.look<1>(v), 8),
+           s3 = c.p[3] ^ L.look<0>(v);
+#pragma unroll
+  for (int r = 2; r < 14; r++) {
+    const uint32_t t0 = aes_col(L, s0, s1, s2, s3, rk[4 * r]);
+    const uint32_t t1 = aes_col(L, s1, s2, s3, s0, rk[4 * r + 1]);
+    const uint32_t t2 = aes_col(L, s2, s3, s0, s1, rk[4 * r + 2]);
+    const uint32_t t3 = aes_col(L, s3, s0, s1, s2, rk[4 * r + 3]);
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+  out[0] = aes_col_last(L, s0, s1, s2, s3, rk[56]);
+  out[1] = aes_col_last(L, s1, s2, s3, s0, rk[57]);
+  out[2] = aes_col_last(L, s2, s3, s0, s1, rk[58]);
+  out[3] = aes_col_last(L, s3, s0, s1, s2, rk[59]);
 }
 
 }  // namespace ky

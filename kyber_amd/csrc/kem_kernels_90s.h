@@ -164,12 +164,13 @@ __global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_
   uint32_t rk[60];
   ld32B(small + (size_t)inst * SMALL + seed_off, key);
   aes256_expand(L, key, rk);
+  const AesCtr cx = aes256ctr_init(L, rk, (uint32_t)nonce);
   uint8_t* out = prf + ((size_t)inst * njobs_per_inst + nonce) * P::PRF_STRIDE;
   const int nblk = (P::ETA1 == 3 && nonce < n_eta1) ? 12 : 8;
 #pragma unroll 1
   for (int b = 0; b < nblk; b++) {
     uint32_t o[4];
-    aes256ctr_block(L, rk, (uint32_t)nonce, (uint32_t)b, o);
+    aes256ctr_block(L, rk, cx, (uint32_t)b, o);
     *reinterpret_cast<uint4*>(out + 16 * b) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
   uint32_t rk[60];
   ld32B(rho + (size_t)inst * rho_stride, key);
   aes256_expand(L, key, rk);
+  const AesCtr cx = aes256ctr_init(L, rk, x | y << 8);
 
   uint32_t* row = stage + (wave * 64 + lane) * STAGE90_DW;
   const uint32_t row_addr = lds_addr(row);
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
 #pragma unroll 1
     for (int b = 0; b < XOF90_BLOCKS; b++) {
       uint32_t o[4];
-      aes256ctr_block(L, rk, x | y << 8, blk + b, o);
+      aes256ctr_block(L, rk, cx, blk + b, o);
       // H[4b..4b+3] = o, with a compile-time destination (b is a run-time loop index)
 #pragma unroll
       for (int bb = 0; bb < XOF90_BLOCKS; bb++)
