@@ -122,3 +122,26 @@ def test_calls_on_different_streams_do_not_race_on_the_workspace():
         torch.cuda.synchronize()
         assert torch.equal(ct1, want1) and torch.equal(ss1, want_s1)
         assert torch.equal(ct2, want2) and torch.equal(ss2, want_s2) and torch.equal(back, want_s2)
+
+
+def test_polynomial_kernel_properties_at_full_size():
+    """2^20 polynomials: linearity of the NTT mod q, commutativity of the base
+    multiplication mod q, and the fused product equal to the three separate
+    kernels bit for bit (ntt, ntt, basemul, Barrett, invntt_tomont)."""
+    n, Q = 1 << 20, 3329
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2025)
+    a = torch.randint(0, Q, (n, 256), dtype=torch.int16, device="cuda", generator=g)
+    b = torch.randint(-(Q // 2), Q // 2 + 1, (n, 256), dtype=torch.int16, device="cuda", generator=g)
+    s = ((a.to(torch.int32) + b.to(torch.int32)) % Q).to(torch.int16)
+    ta, tb, ts = kl.poly_ntt_(a.clone()), kl.poly_ntt_(b.clone()), kl.poly_ntt_(s)
+    assert torch.equal((ta.to(torch.int32) + tb.to(torch.int32)) % Q, ts.to(torch.int32) % Q)
+    ab = kl.poly_basemul(torch.empty_like(a), ta, tb)
+    ba = kl.poly_basemul(torch.empty_like(a), tb, ta)
+    assert torch.equal(ab.to(torch.int32) % Q, ba.to(torch.int32) % Q)
+    fused = kl.poly_mul_fused(torch.empty_like(a), a, b)
+    # the separate path: Barrett-reduce the product (values are in (-2q, 2q)) exactly as poly_reduce does
+    red = ab.to(torch.int32)
+    t = (20159 * red + (1 << 25)) >> 26
+    red = (red - t * Q).to(torch.int16)
+    assert torch.equal(kl.poly_invntt_(red), fused)
