@@ -11,6 +11,7 @@
 #define KYBER_HARNESS_COMMON_H
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------- surf */

@@ -86,3 +86,10 @@ def test_reference_functional_tests_on_gpu(name):
     out = _run(os.path.join(H, "test_kex_hip"), name).decode()
     assert out == ("KEX_UAKE_SENDABYTES: %d\nKEX_UAKE_SENDBBYTES: %d\nKEX_AKE_SENDABYTES: %d\nKEX_AKE_SENDBBYTES: %d\n"
                    % (pkb + ctb, ctb, pkb + ctb, 2 * ctb))
+
+
+@pytest.mark.gpu
+def test_link_time_randombytes_hook():
+    """a program's own randombytes replaces the library's weak one, as the
+    reference's harnesses do (ref/randombytes.h:7, ref/test_vectors.c:41)"""
+    assert _run(os.path.join(H, "test_randombytes_hook")).decode() == "randombytes hook: OK\n"
