@@ -4,6 +4,7 @@
 // this file: every result is produced by the gfx950 kernels in kem_kernels.h,
 // kem_kernels_90s.h and arith_kernels.h (the latter through arith_launch.h).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <map>
@@ -46,9 +47,18 @@ struct Workspace {
   bool used = false;
 };
 Workspace g_ws[MAX_DEV];
-size_t g_chunk = DEFAULT_CHUNK;
-size_t g_tail_cap_max = (size_t)-1;
-std::mutex g_mu;
+std::atomic<size_t> g_chunk{DEFAULT_CHUNK};
+std::atomic<size_t> g_tail_cap_max{(size_t)-1};
+// One lock per device (workspace + launch order), so that host threads driving
+// different GPUs do not serialise each other.  Indexed by the calling thread's
+// current device.
+std::mutex g_dev_mu[MAX_DEV];
+std::mutex g_prof_mu;
+inline std::mutex& dev_mutex(std::mutex (&arr)[MAX_DEV]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+  return arr[dev];
+}
 
 int ws_reserve(size_t bytes, uint8_t** out) {
   int dev = 0;
@@ -119,7 +129,8 @@ struct Layout {
     smat = reinterpret_cast<int16_t*>(small + chunk * SMALL + tq);
     hpk = reinterpret_cast<uint8_t*>(smat) + MAT;
     const size_t cap = tailq_capacity(chunk * P::NMAT);
-    tail_cap = (uint32_t)(cap < g_tail_cap_max ? cap : g_tail_cap_max);
+    const size_t cap_max = g_tail_cap_max.load();
+    tail_cap = (uint32_t)(cap < cap_max ? cap : cap_max);
     return 0;
   }
 };
@@ -158,6 +169,7 @@ inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
   hipEvent_t b;
   (void)hipEventCreate(&b);
   (void)hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(ProfRec{name, a, b});
 }
 #define RUN(name, st, ...)        \
@@ -194,9 +206,10 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 // ---- the three pipelines (device pointers) -----------------------------------
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
-  const size_t chunk = n < g_chunk ? n : g_chunk;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
@@ -227,9 +240,10 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
 // with n copies of the key.
 template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
-  const size_t chunk = n < g_chunk ? n : g_chunk;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
   const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
@@ -271,9 +285,10 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 // sk_stride == 0: n ciphertexts for ONE secret key, matrix expanded once.
 template <class P, bool N90>
 int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
-  const size_t chunk = n < g_chunk ? n : g_chunk;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
   const bool shared = sk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
@@ -487,14 +502,14 @@ struct Streams {
 
 // Streams, events and the staging allocation are kept per device between calls
 // (small batches would otherwise spend most of their time creating them); host
-// calls on one device are serialised by g_host_mu.
+// calls on one device are serialised by that device's g_host_mu entry.
 struct HostCtx {
   Streams S;
   uint8_t* staging = nullptr;
   size_t cap = 0;
 };
 HostCtx* g_host[MAX_DEV] = {};
-std::mutex g_host_mu;
+std::mutex g_host_mu[MAX_DEV];
 
 int host_ctx(size_t bytes, HostCtx** out) {
   int dev = 0;
@@ -526,7 +541,7 @@ int host_ctx(size_t bytes, HostCtx** out) {
 // f(m, in[], out[], stream): the device-pointer routine for one pass of m instances
 template <class F>
 int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer_list<HostOut> outs_, F&& f) {
-  std::lock_guard<std::mutex> hlk(g_host_mu);
+  std::lock_guard<std::mutex> hlk(dev_mutex(g_host_mu));
   const std::vector<HostIn> ins(ins_);
   const std::vector<HostOut> outs(outs_);
   const size_t pass = n < HOST_PASS ? n : HOST_PASS;
@@ -911,21 +926,19 @@ void kyber_hip_host_free(void* p) {
 }
 
 int kyber_hip_set_chunk(size_t instances) {
-  std::lock_guard<std::mutex> lk(g_mu);
   if (instances > ((size_t)1 << 24)) return KYBER_HIP_EINVAL;  // chunk * K^2 matrix entries are indexed with int
   g_chunk = instances ? instances : DEFAULT_CHUNK;
   return 0;
 }
 
 int kyber_hip_set_tail_capacity(size_t records) {
-  std::lock_guard<std::mutex> lk(g_mu);
   g_tail_cap_max = records;
   return 0;
 }
 
 int kyber_hip_release(void) {
-  std::lock_guard<std::mutex> hlk(g_host_mu);  // same order as the host-pointer calls: host lock, then workspace lock
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> hlk(dev_mutex(g_host_mu));  // same order as the host-pointer calls: host lock, then workspace lock
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
@@ -947,7 +960,7 @@ int kyber_hip_release(void) {
 const char* kyber_hip_last_error(void) { return g_err; }
 
 int kyber_hip_profile_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
@@ -958,7 +971,7 @@ int kyber_hip_profile_enable(int on) {
 }
 
 int kyber_hip_profile_read(char* buf, size_t len) {
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   HIP_TRY(hipDeviceSynchronize());
   std::map<std::string, std::pair<double, long>> agg;
   for (auto& r : g_prof) {

@@ -145,3 +145,38 @@ def test_polynomial_kernel_properties_at_full_size():
     t = (20159 * red + (1 << 25)) >> 26
     red = (red - t * Q).to(torch.int16)
     assert torch.equal(kl.poly_invntt_(red), fused)
+
+
+def test_concurrent_host_threads_on_one_device(oracle):
+    """Four host threads call the host-pointer API at once (ctypes releases the
+    GIL): the per-device locks serialise them, every result is the
+    single-threaded one."""
+    import threading
+    kem = kyber_amd.KyberHip(2)
+    rng = np.random.default_rng(4)
+    n = 3000
+    kcs = [rng.integers(0, 256, (n, 64), dtype=np.uint8) for _ in range(4)]
+    ecs = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for _ in range(4)]
+    want = []
+    for kc, ec in zip(kcs, ecs):
+        pk, sk = kem.keypair(kc)
+        ct, ss = kem.enc(pk, ec)
+        want.append((pk, sk, ct, ss))
+    got = [None] * 4
+
+    def work(i):
+        pk, sk = kem.keypair(kcs[i])
+        ct, ss = kem.enc(pk, ecs[i])
+        got[i] = (pk, sk, ct, ss, kem.dec(ct, sk))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(4):
+        for a, b in zip(got[i][:4], want[i]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(got[i][4], want[i][3])
+    idx = np.arange(0, n, 500)
+    assert np.array_equal(want[0][0][idx], oracle.keypair(2, kcs[0][idx])[0])
