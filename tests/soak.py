@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Soak test: GPU against the reference's own compiled code (oracle/_ref, avx2 or
 ref) on millions of random instances per parameter set, every byte compared.
-Test infrastructure (uses tests/oracle_lib.py); not part of the product.
+Test infrastructure (uses oracle_lib.py beside it), run by hand, not collected by pytest.
 
-    python3 tools/soak.py [seconds per set = 60] [batch = 2^19]
+    python3 tests/soak.py [seconds per set = 60] [batch = 2^19]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this directory
 import kyber_amd  # noqa: E402
 import oracle_lib  # noqa: E402
 
