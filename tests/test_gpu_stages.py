@@ -153,3 +153,20 @@ def test_namespaced_single_call_api(oracle):
     want = oracle.dec(3, np.frombuffer(bytes(ct), np.uint8), np.frombuffer(bytes(sk), np.uint8))
     assert bytes(want[0]) == bytes(ss)
     assert bytes(sk)[384 * 3:384 * 3 + pkb] == bytes(pk)  # sk embeds pk (ref/kem.c:28-29)
+
+
+def test_release_and_profile_housekeeping(oracle):
+    """kyber_hip_release drops the workspace, streams and staging; the next call
+    rebuilds them.  The profiling hook reports every kernel of a call."""
+    kem = kyber_amd.KyberHip(3)
+    kc = np.random.default_rng(8).integers(0, 256, (50, 64), dtype=np.uint8)
+    pk0, sk0 = kem.keypair(kc)
+    assert kl.library().kyber_hip_release() == 0
+    assert kl.library().kyber_hip_release() == 0          # idempotent
+    kl.profile_enable(True)
+    pk1, sk1 = kem.keypair(kc)
+    prof = kl.profile_read()
+    kl.profile_enable(False)
+    assert np.array_equal(pk0, pk1) and np.array_equal(sk0, sk1)
+    assert {"k_kp_pre", "k_sample_matrix", "k_sample_matrix_tail", "k_prf", "k_kp_arith", "k_kp_post"} <= set(prof)
+    assert all(cnt == 1 and ms >= 0 for cnt, ms in prof.values())
