@@ -10,14 +10,24 @@ by the batched keypair before the timed region).  B defaults to 2^20 per GPU
 disjoint batches with no data-path collective ("weak" scaling); the only
 torch.distributed traffic is the barrier and the max-over-ranks of the time.
 
+--gpus N with N > 1 and no WORLD_SIZE in the environment: this process touches
+no GPU and starts N rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits
+with the worst child status.  Under torchrun (WORLD_SIZE set) it is one rank.
+Either way the line is printed only if the world that ran equals --gpus.
+
 Prints ONE JSON line (rank 0) with the whole-job rate, a `roofline` object for
 the dominant kernel (k_sample_matrix: SHAKE128 matrix expansion + rejection
-sampling) measured live with HIP events, and a `cpu_baseline` object: the
-reference's own avx2/ (or ref/) code from oracle/_ref timed on the host cores.
+sampling) measured live with HIP events, an `ntt` object (BASELINE.json
+configs[1], the second half of its metric), a `pcie_inclusive` object (the
+host-pointer entry points, never the headline) and a `cpu_baseline` object:
+the reference's own avx2/ and ref/ code from oracle/_ref timed on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -34,7 +44,7 @@ WORKLOADS = {  # name: (k, nineties, compulsory enc+dec bytes, Keccak-f per enc+
 }
 SEED0 = 0x4B59424552  # "KYBER", SURVEY.md §8(d)
 
-# algorithmic constants (restated in DESIGN.md)
+# algorithmic constants (restated in DESIGN.md §4)
 DEFAULT_CHUNK = 1 << 19            # kyber_hip.hip: instances per internal pass = units per launch
 KECCAK_LANE_OPS = 6240           # 32-bit lane-ops per Keccak-f[1600] as written in the reference
 VALU_PEAK_TLOPS = 78.6           # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, full-rate 32-bit int ops
@@ -42,7 +52,28 @@ HBM_PEAK_GBS = 8000.0
 ENCDEC_BYTES = 5856              # compulsory HBM bytes per Kyber768 enc+dec
 ENCDEC_PERMS = 100               # Keccak-f per Kyber768 enc+dec
 MATRIX_ENTRY_PERMS = 3           # SHAKE128 blocks per matrix entry (4th block: 0.8 % of entries)
-MATRIX_ENTRY_BYTES = 512 + 32 / 9.0
+# 90s sets: 32-bit lane-ops of the textbook word-oriented forms
+AES_BLOCK_LANE_OPS = 680         # AES-256 on one 16-byte block: 14 rounds x (16 look-ups + 16 byte selects + 16 xors) + whitening
+SHA256_BLOCK_LANE_OPS = 2160     # 64 rounds x 24 + 48 schedule words x 13
+SHA512_BLOCK_LANE_OPS = 5504     # 80 rounds x 24 x 2 + 64 schedule words x 13 x 2 (64-bit words on 32-bit lanes)
+AES_MATRIX_ENTRY_BLOCKS = 32     # ref/indcpa.c:160-162,182: 8 x 64-byte XOF blocks before the first test
+# polynomial kernels: lane-ops per transform
+NTT_LANE_OPS, INVNTT_LANE_OPS, BASEMUL_LANE_OPS = 5400, 9000, 2800
+
+
+def lane_ops_per_encdec(k, n90):
+    """Algorithmic 32-bit lane-ops of one encaps + one decaps (symmetric part only, as SURVEY §8(d) prices it)."""
+    if not n90:
+        return WORKLOADS["kyber%d" % (256 * k)][3] * KECCAK_LANE_OPS
+    pkb, ctb = 384 * k + 32, 32 * ((11 if k == 4 else 10) * k + (5 if k == 4 else 4))
+    sha256_blocks = lambda nbytes: (nbytes + 9 + 63) // 64
+    prf_blocks = lambda eta: (64 * eta) // 16
+    eta1 = 3 if k == 2 else 2
+    enc_core = k * k * AES_MATRIX_ENTRY_BLOCKS + k * prf_blocks(eta1) + (k + 1) * prf_blocks(2)  # gen_matrix + noise
+    aes = 2 * enc_core                                                   # encaps + decaps' re-encryption
+    s256 = sha256_blocks(32) + sha256_blocks(pkb) + 2 * (sha256_blocks(ctb) + sha256_blocks(64))  # H(m0), H(pk), 2 x (H(ct), KDF)
+    s512 = 2                                                             # G in encaps and decaps
+    return aes * AES_BLOCK_LANE_OPS + s256 * SHA256_BLOCK_LANE_OPS + s512 * SHA512_BLOCK_LANE_OPS
 
 
 def pmc_traffic(kernel, k, chunk):
@@ -66,85 +97,106 @@ def pmc_traffic(kernel, k, chunk):
     return None, None
 
 
+def host_threads():
+    """Threads for the CPU leg: the CPUs this process may run on, bounded by the
+    box's per-job CPU share when the harness exports one (OMP_NUM_THREADS)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
+
+
 def cpu_baseline(budget_s=20.0, sample=None):
     """The CPU leg (the only place this program touches oracle/): time the
-    reference's own code (oracle/_ref, built from /root/reference's ref/ and
-    avx2/ sources; falls back to the oracle port) on the host cores, and check
-    a strided sample of what the GPU just produced against the same code.
-    sample = dict(kc, ec, pk, sk, ct, ss) of numpy arrays, or None."""
+    reference's own code (oracle/_ref, built from /root/reference's avx2/ and
+    ref/ sources; falls back to the oracle port) on the host cores, one leg per
+    implementation, and check a strided sample of what the GPU just produced
+    against the same code.  sample = dict(kc, ec, pk, sk, ct, ss) of numpy arrays, or None."""
     import numpy as np
     import oracle_lib
 
-    threads = min(16, os.cpu_count() or 1)
+    threads = host_threads()
     rng = np.random.default_rng(7)
-    kind, impl, lib = "port", "oracle", None
+    legs = []
     for cand in (("avx2",) if oracle_lib.has_avx2() else ()) + ("ref",):
         try:
-            lib = oracle_lib.RefLib(cand, K, N90)
-            kind, impl = "reference", cand
-            break
+            legs.append((cand, "reference", oracle_lib.RefLib(cand, K, N90)))
         except (OSError, FileNotFoundError):
             continue
-    if lib is None:
+    if not legs:
         o = oracle_lib.load_oracle()
 
         class _Port:
             def keypair(self, c): return o.keypair(K, c, N90)
             def enc(self, pk, c): return o.enc(K, pk, c, N90)
             def dec(self, ct, sk): return o.dec(K, ct, sk, N90)
-        lib = _Port()
+        legs.append(("oracle", "port", _Port()))
 
     sample_ok = None
     if sample is not None:
+        lib = legs[0][2]
         spk, ssk = lib.keypair(sample["kc"])
         sct, sss = lib.enc(spk, sample["ec"])
         sample_ok = bool(np.array_equal(spk, sample["pk"]) and np.array_equal(ssk, sample["sk"])
                          and np.array_equal(sct, sample["ct"]) and np.array_equal(sss, sample["ss"])
                          and np.array_equal(lib.dec(sct, ssk), sample["ss"]))
-        assert sample_ok, "strided sample of the GPU results differs from the %s code" % kind
+        assert sample_ok, "strided sample of the GPU results differs from the %s code" % legs[0][1]
 
-    # calibrate on one core
-    n0 = 512
-    kc, ec = rng.integers(0, 256, (n0, 64), dtype=np.uint8), rng.integers(0, 256, (n0, 32), dtype=np.uint8)
-    pk, sk = lib.keypair(kc)
-    t0 = time.perf_counter()
-    ct, ss = lib.enc(pk, ec)
-    ss2 = lib.dec(ct, sk)
-    t1 = time.perf_counter() - t0
-    assert (ss == ss2).all()
-    one_core = n0 / t1
-    per_thread = max(n0, int(one_core * budget_s * 0.5))
-    kc = rng.integers(0, 256, (per_thread, 64), dtype=np.uint8)
-    ec = rng.integers(0, 256, (per_thread, 32), dtype=np.uint8)
-    pk, sk = lib.keypair(kc)
+    def time_leg(lib, budget):
+        n0 = 256  # calibrate on one core
+        kc, ec = rng.integers(0, 256, (n0, 64), dtype=np.uint8), rng.integers(0, 256, (n0, 32), dtype=np.uint8)
+        pk, sk = lib.keypair(kc)
+        t0 = time.perf_counter()
+        ct, ss = lib.enc(pk, ec)
+        ss2 = lib.dec(ct, sk)
+        t1 = time.perf_counter() - t0
+        assert (ss == ss2).all()
+        one_core = n0 / t1
+        per_thread = max(n0, int(one_core * budget * 0.5))
+        kc = rng.integers(0, 256, (per_thread, 64), dtype=np.uint8)
+        ec = rng.integers(0, 256, (per_thread, 32), dtype=np.uint8)
+        pk, sk = lib.keypair(kc)
 
-    def work():
-        c, s = lib.enc(pk, ec)
-        lib.dec(c, sk)
+        def work():
+            c, s = lib.enc(pk, ec)
+            lib.dec(c, sk)
 
-    ths = [threading.Thread(target=work) for _ in range(threads)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    return {
-        "value": threads * per_thread / dt, "unit": "encaps+decaps/s", "cores": threads, "kind": kind,
-        "impl": impl, "one_core": one_core,
-        "sample": "enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt),
-        "gpu_sample_bit_exact": sample_ok,
-    }
+        ths = [threading.Thread(target=work) for _ in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        return {"value": threads * per_thread / dt, "one_core": one_core,
+                "sample": "enc+dec, %d instances per thread x %d threads (%.1f s)" % (per_thread, threads, dt)}
+
+    out = None
+    per_leg = budget_s / len(legs)
+    for impl, kind, lib in legs:
+        r = time_leg(lib, per_leg)
+        r.update({"unit": "encaps+decaps/s", "cores": threads, "kind": kind, "impl": impl})
+        if out is None:  # the first (fastest) implementation is the baseline object; the others ride along
+            out = dict(r)
+            out["host_cpus"] = os.cpu_count()
+            out["gpu_sample_bit_exact"] = sample_ok
+            out["legs"] = {}
+        out["legs"][impl] = {"value": r["value"], "one_core": r["one_core"], "cores": threads, "kind": kind, "sample": r["sample"]}
+    return out
 
 
-def bench_ntt(args):
+# ---------------------------------------------------------------------------- config 2: polynomial kernels
+def measure_ntt(n, steps, warmup):
     """BASELINE.json configs[1]: batched forward NTT / basemul / inverse NTT on
-    2^20 polynomials (int16[256]) resident in HBM; one JSON line."""
+    n polynomials (int16[256]) resident in HBM.  -> dict per kernel with
+    polys/s, GB/s and both roofline fractions."""
     import torch
     from kyber_amd import lib as kl
-    assert torch.cuda.is_available()
-    dev = torch.device("cuda", 0)
-    n = args.batch
+    dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev)
     g.manual_seed(SEED0)
     a = torch.randint(0, 3329, (n, 256), dtype=torch.int16, device=dev, generator=g)
@@ -152,34 +204,111 @@ def bench_ntt(args):
     r = torch.empty_like(a)
     res = {}
 
-    def timed(name, fn, nbytes):
-        for _ in range(args.warmup):
+    def timed(name, fn, nbytes, lane_ops):
+        for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
+        e0.record()  # the kernels are launched on torch's current stream (kyber_amd.lib._torch_stream)
+        for _ in range(steps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.steps
+        ms = e0.elapsed_time(e1) / steps
         res[name] = {"ms": ms, "polys_per_s": n / (ms * 1e-3), "GBps": n * nbytes / (ms * 1e-3) * 1e-9,
-                     "hbm_frac": n * nbytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS}
+                     "hbm_frac": n * nbytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
+                     "valu_frac": n * lane_ops / (ms * 1e-3) * 1e-12 / VALU_PEAK_TLOPS}
 
     work = a.clone()
-    timed("poly_ntt", lambda: kl.poly_ntt_(work), 1024)
-    timed("poly_invntt", lambda: kl.poly_invntt_(work), 1024)
-    timed("poly_basemul", lambda: kl.poly_basemul(r, a, b), 1536)
-    timed("poly_mul_fused(ntt,ntt,basemul,invntt)", lambda: kl.poly_mul_fused(r, a, b), 1536)
+    timed("poly_ntt", lambda: kl.poly_ntt_(work), 1024, NTT_LANE_OPS)
+    timed("poly_invntt", lambda: kl.poly_invntt_(work), 1024, INVNTT_LANE_OPS)
+    timed("poly_basemul", lambda: kl.poly_basemul(r, a, b), 1536, BASEMUL_LANE_OPS)
+    timed("poly_mul_fused", lambda: kl.poly_mul_fused(r, a, b), 1536, 2 * NTT_LANE_OPS + BASEMUL_LANE_OPS + INVNTT_LANE_OPS)
+    return res
+
+
+def bench_ntt(args):
+    import torch
+    assert torch.cuda.is_available()
+    res = measure_ntt(args.batch, args.steps, args.warmup)
     fwd = res["poly_ntt"]
     print(json.dumps({
         "metric": "batched NTTs/sec per GPU", "value": fwd["polys_per_s"], "unit": "NTT/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": fwd["ms"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-        "config": {"workload": "forward NTT (poly_ntt) on %d polynomials of Z_3329[X]/(X^256+1), in place in HBM" % n},
+        "config": {"workload": "forward NTT (poly_ntt) on %d polynomials of Z_3329[X]/(X^256+1), in place in HBM" % args.batch},
         "roofline": {"kernel": "k_poly_ntt", "bound": "hbm", "achieved": fwd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": fwd["hbm_frac"], "traffic": None},
         "kernels": res}), flush=True)
+
+
+def measure_pcie(kem, n=1 << 17):
+    """PCIe-inclusive rate: the host-pointer entry points on pinned host arrays
+    (H2D of pk/coins, D2H of ct/ss, H2D of ct/sk, D2H of ss inside the timed
+    region).  Never the headline value."""
+    import ctypes
+    import numpy as np
+    from kyber_amd import lib as kl
+    L = kl.library()
+    rng = np.random.default_rng(1)
+    kc, ec = rng.integers(0, 256, (n, 64), dtype=np.uint8), rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk0, sk0 = kem.keypair(kc)
+    pk, sk, pec = kl.pinned_empty(pk0.shape), kl.pinned_empty(sk0.shape), kl.pinned_empty(ec.shape)
+    pk[:], sk[:], pec[:] = pk0, sk0, ec
+    ct, ss, ss2 = kl.pinned_empty((n, kem.ct_bytes)), kl.pinned_empty((n, 32)), kl.pinned_empty((n, 32))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = L.kyber_batch_enc(kem.k, kem.nineties, n, p(ct), p(ss), p(pk), p(pec))
+        rc |= L.kyber_batch_dec(kem.k, kem.nineties, n, p(ss2), p(ct), p(sk))
+        dt = time.perf_counter() - t0
+        assert rc == 0 and np.array_equal(ss, ss2)
+        best = dt if best is None else min(best, dt)
+    bytes_moved = n * (kem.pk_bytes + 32 + kem.ct_bytes + 32 + kem.ct_bytes + kem.sk_bytes + 32)
+    return {"value": n / best, "unit": "encaps+decaps/s", "instances": n, "host_memory": "pinned",
+            "link_GBps": bytes_moved / best * 1e-9,
+            "note": "kyber_batch_enc + kyber_batch_dec on host pointers, copies inside the timed region; not the headline"}
+
+
+# ---------------------------------------------------------------------------- launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """--gpus N outside torchrun: start N rank processes of this script.  The
+    parent must not initialise the GPU (no torch import here)."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def load_engine(args):
+    """The HIP engine.  KYBER_BENCH_ENGINE=module:factory (tests only; needs
+    --device cpu) substitutes a stand-in so the N-rank plumbing can be rehearsed
+    without a GPU; without it a missing library or GPU is an error."""
+    spec = os.environ.get("KYBER_BENCH_ENGINE")
+    if args.device == "cpu":
+        if not spec:
+            raise SystemExit("bench.py: --device cpu is a plumbing rehearsal and needs KYBER_BENCH_ENGINE; the product has no CPU path")
+        mod, fn = spec.split(":")
+        return getattr(__import__(mod), fn)(K, N90), None
+    import kyber_amd
+    from kyber_amd import lib as kl
+    return kyber_amd.KyberHip(K, N90), kl
 
 
 def main():
@@ -189,40 +318,60 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="KEM instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-measurements", action="store_true", help="skip the ntt and pcie_inclusive objects")
     ap.add_argument("--chunk", type=int, default=0, help="instances per internal pass (0 = library default)")
     ap.add_argument("--shared-key", action="store_true",
                     help="side measurement: every instance uses ONE key pair (kyber_batch_enc_shared_pk / dec_shared_sk)")
     ap.add_argument("--workload", default="kyber768", choices=sorted(WORKLOADS) + ["ntt"],
                     help="default kyber768 = BASELINE.json's metric; others are side measurements")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu: N-rank plumbing rehearsal with a stand-in engine (tests)")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help="default nccl (RCCL) on cuda, gloo on cpu")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses device 0 (RCCL refuses two ranks on one GPU, so use --dist-backend gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     if args.workload == "ntt":
         return bench_ntt(args)
     global K, N90, ENCDEC_BYTES, ENCDEC_PERMS
     K, N90, ENCDEC_BYTES, ENCDEC_PERMS = WORKLOADS[args.workload]
     set_name = "Kyber%d%s" % (256 * K, "-90s" if N90 else "")
 
-    import numpy as np
     import torch
-    import kyber_amd
-    from kyber_amd import lib as kl
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        devidx = 0 if args.ranks_share_device else local
+        torch.cuda.set_device(devidx)
+        dev = torch.device("cuda", devidx)
+    else:
+        dev = torch.device("cpu")
+    backend = args.dist_backend or ("nccl" if on_gpu else "gloo")
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun, also with one rank, so the RCCL path can be rehearsed on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def barrier():
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    dev = torch.device("cuda", local)
-    kem = kyber_amd.KyberHip(K, N90)
+    kem, kl = load_engine(args)
     if args.chunk:
         kl.set_chunk(args.chunk)
     n = args.batch
@@ -253,7 +402,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -269,7 +418,7 @@ def main():
     # per-kernel durations: a separate, untimed pass with HIP events on the launch stream
     roof = None
     kernels = {}
-    if rank == 0:
+    if rank == 0 and kl is not None:
         kl.profile_enable(True)
         reps = 3
         for _ in range(reps):
@@ -283,12 +432,17 @@ def main():
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
         chunk = min(n, args.chunk or DEFAULT_CHUNK)
-        if dom in ("k_sample_matrix", "k90_sample_matrix"):
-            entries = chunk * K * K
-            ops = entries * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS
-            bytes_ = entries * MATRIX_ENTRY_BYTES
+        if dom == "k_sample_matrix":
+            units, unit_name = chunk * K * K, "matrix entries"
+            ops = units * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS
+            bytes_ = units * (512 + 32.0 / (K * K))
+        elif dom == "k90_sample_matrix":
+            units, unit_name = chunk * K * K, "matrix entries"
+            ops = units * AES_MATRIX_ENTRY_BLOCKS * AES_BLOCK_LANE_OPS
+            bytes_ = units * (512 + 32.0 / (K * K))
         else:  # fall back to whole-pipeline accounting for an unexpected dominant kernel
-            ops = chunk * ENCDEC_PERMS * KECCAK_LANE_OPS
+            units, unit_name = chunk, "instances (whole enc+dec accounting)"
+            ops = chunk * lane_ops_per_encdec(K, N90)
             bytes_ = chunk * ENCDEC_BYTES
         ach = ops / avg_s * 1e-12
         traffic, traffic_src = pmc_traffic(dom, K, chunk)
@@ -296,31 +450,43 @@ def main():
             "kernel": dom, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
             "frac": ach / VALU_PEAK_TLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes": bytes_, "avg_launch_ms": avg_s * 1e3,
-            "units_per_launch": chunk * K * K if dom.endswith("sample_matrix") else chunk,
+            "units_per_launch": units, "unit_name": unit_name,
             "hbm": {"achieved": bytes_ / avg_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes_ / avg_s * 1e-9 / HBM_PEAK_GBS},
         }
 
     if rank == 0:
+        assert world == args.gpus
         total = n * world * args.steps
         value = total / dt
         out = {
             "metric": "%s encaps+decaps/sec%s" % (set_name, " (one shared key pair)" if args.shared_key else ""), "value": value, "unit": "encaps+decaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (Keccak lanes as 2x32 bit) + f32 (exact integer polynomial arithmetic)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("u32 (AES/SHA-2 words)" if N90 else "u32 (Keccak lanes as 2x32 bit)") + " + f32 (exact integer polynomial arithmetic)",
             "data": "synthetic (device-generated coins, seed 0x4B59424552)",
             "config": {"workload": "%s batched encaps+decaps%s, %d instances per GPU per step, device-resident"
                        % (set_name, " with one shared key pair" if args.shared_key else "", n),
-                       "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective"},
+                       "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective",
+                       "dist_backend": backend if dist is not None else None},
             "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_cpu_reference": parity},
-            "pipeline": {"valu_frac": value / world * ENCDEC_PERMS * KECCAK_LANE_OPS * 1e-12 / VALU_PEAK_TLOPS,
-                         "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS},
+            "pipeline": {"valu_frac": value / world * lane_ops_per_encdec(K, N90) * 1e-12 / VALU_PEAK_TLOPS,
+                         "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS,
+                         "lane_ops_per_encdec": lane_ops_per_encdec(K, N90)},
             "roofline": roof, "kernels": kernels,
         }
-        if N90:  # the Keccak lane-op constant does not describe the AES/SHA-2 sets
-            out["pipeline"]["valu_frac"] = None
-            if roof:
-                roof.update({"achieved": None, "frac": None})
+        if kl is None:
+            out["engine"] = os.environ.get("KYBER_BENCH_ENGINE")
+        if on_gpu and kl is not None and world == 1 and not args.no_side_measurements and not args.shared_key:
+            try:
+                out["ntt"] = measure_ntt(1 << 20, 10, 2)  # BASELINE.json configs[1]
+                out["ntt"]["config"] = "2^20 polynomials int16[256] in HBM; fused = ntt(a), ntt(b), basemul, invntt in one kernel"
+            except Exception as e:
+                out["ntt"] = {"error": repr(e)}
+            try:
+                out["pcie_inclusive"] = measure_pcie(kem)
+            except Exception as e:
+                out["pcie_inclusive"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(sample=sample)
@@ -333,7 +499,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
