@@ -67,8 +67,11 @@ int kyber_batch_dec(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *c
  * Every pointer is device memory on the current HIP device (coins must not be
  * NULL); work is enqueued on `stream` (a hipStream_t passed as void*, NULL =
  * default stream) and the call returns without synchronising.  The internal
- * workspace is per device and grows on demand; calls on one device must not
- * overlap in time. */
+ * workspace is one per device and grows on demand; calls on one device -- from
+ * any thread, on any stream -- are serialised by the library: a per-device lock
+ * orders the launches and each call's stream first waits for an event recorded
+ * behind the previous call's last kernel, so they may be issued concurrently
+ * but do not run concurrently. */
 int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins, void *stream);
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, void *stream);
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
@@ -145,7 +148,9 @@ KYBER_HIP_DECLARE_SET(kyber1024_90s)
  *   ntt        in place, = poly_ntt            ref/poly.c:244-248 (ntt + Barrett)
  *   invntt     in place, = poly_invntt_tomont  ref/poly.c:259-262
  *   basemul    r = a o b, = poly_basemul_montgomery  ref/poly.c:273-280
- *   mul_fused  r = invntt_tomont(poly_reduce(poly_ntt(a) o poly_ntt(b))) in one kernel */
+ *   mul_fused  r = invntt_tomont(poly_reduce(poly_ntt(a) o poly_ntt(b))) in one kernel
+ * r may be the same array as a or b (polynomial i of r depends on polynomial i
+ * of a and b only); partially overlapping arrays are not supported. */
 int kyber_batch_poly_ntt_dev(size_t npoly, int16_t *r, void *stream);
 int kyber_batch_poly_invntt_dev(size_t npoly, int16_t *r, void *stream);
 int kyber_batch_poly_basemul_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);

@@ -259,8 +259,11 @@ __global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restr
   uint4* dst = reinterpret_cast<uint4*>(ct + (size_t)inst0 * P::CTB);
   for (int o = threadIdx.x; o < nvalid * (P::CTB / 16); o += 256) {
     if constexpr (CMP) {
+      // ref/verify.c:16-25: OR-reduce of the XOR, no branch on the (secret-dependent) result --
+      // every 16-byte block issues the same LDS atomic whatever it found
       uint4 x = src[o], y = dst[o];
-      if ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) atomicOr(&bad[o / (P::CTB / 16)], 1u);
+      const uint32_t d = (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+      atomicOr(&bad[o / (P::CTB / 16)], (d | (0u - d)) >> 31);
     } else {
       dst[o] = src[o];
     }
@@ -380,8 +383,7 @@ __global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __rest
 }
 
 // r = a o b (Montgomery domain), no reduction beyond basemul's own.  ref/poly.c:273-280
-__global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
-                                                      const int16_t* __restrict__ b) {
+__global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* r, const int16_t* a, const int16_t* b) {  // r may alias a or b
   __shared__ int ztab[128];
   const Grp w = grp();
   twiddles_to_lds(ztab);
@@ -396,8 +398,7 @@ __global__ void __launch_bounds__(256) k_poly_basemul(long npoly, int16_t* __res
 
 // fused: r = invntt_tomont( poly_ntt(a) o poly_ntt(b) ) -- one HBM round trip
 // per operand, everything else in registers/LDS.
-__global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* __restrict__ r, const int16_t* __restrict__ a,
-                                                        const int16_t* __restrict__ b) {
+__global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* r, const int16_t* a, const int16_t* b) {  // r may alias a or b
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
   __shared__ int ztab[128];
   const Grp w = grp();

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
+#include <strings.h>
 #include <sys/random.h>
 #include <unistd.h>
 
@@ -86,20 +88,33 @@ int ws_reserve(size_t bytes, uint8_t** out) {
 struct WsUse {
   hipStream_t st;
   Workspace* w = nullptr;
+  int rc = 0;  // checked by the caller before it launches anything
   explicit WsUse(hipStream_t s) : st(s) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return;
-    w = &g_ws[dev];
-    if (!w->idle && hipEventCreateWithFlags(&w->idle, hipEventDisableTiming) != hipSuccess) {
-      w->idle = nullptr;
-      w = nullptr;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { rc = hip_fail(e, "hipGetDevice"); return; }
+    if (dev < 0 || dev >= MAX_DEV) { rc = KYBER_HIP_EINVAL; return; }
+    Workspace* ws = &g_ws[dev];
+    if (!ws->idle && (e = hipEventCreateWithFlags(&ws->idle, hipEventDisableTiming)) != hipSuccess) {
+      ws->idle = nullptr;
+      rc = hip_fail(e, "hipEventCreateWithFlags");
       return;
     }
-    if (w->used && w->last != st) (void)hipStreamWaitEvent(st, w->idle, 0);
+    // an unordered second user of the one workspace would corrupt both calls: fail instead
+    if (ws->used && ws->last != st && (e = hipStreamWaitEvent(st, ws->idle, 0)) != hipSuccess) {
+      rc = hip_fail(e, "hipStreamWaitEvent");
+      return;
+    }
+    w = ws;
   }
   ~WsUse() {
     if (!w) return;
-    (void)hipEventRecord(w->idle, st);
+    if (hipEventRecord(w->idle, st) != hipSuccess) {
+      // the next call cannot be ordered behind this one on the device: order it on the host
+      (void)hipStreamSynchronize(st);
+      w->used = false;
+      return;
+    }
     w->last = st;
     w->used = true;
   }
@@ -117,11 +132,10 @@ struct Layout {
   uint32_t tail_cap;
   int16_t* smat;    // shared-key calls: the one expanded matrix
   uint8_t* hpk;     // shared-key calls: H(pk)
-  int carve(size_t chunk) {
-    uint8_t* b;
-    const size_t tq = (tailq_bytes(chunk * P::NMAT) + 255) & ~(size_t)255;
-    int rc = ws_reserve(chunk * PER + tq + MAT + 256, &b);
-    if (rc) return rc;
+  static constexpr size_t tq_bytes(size_t chunk) { return (tailq_bytes(chunk * P::NMAT) + 255) & ~(size_t)255; }
+  static constexpr size_t need(size_t chunk) { return chunk * PER + tq_bytes(chunk) + MAT + 256; }
+  void place(uint8_t* b, size_t chunk) {
+    const size_t tq = tq_bytes(chunk);
     mat = reinterpret_cast<int16_t*>(b);
     prf = b + chunk * MAT;
     small = prf + chunk * PRF;
@@ -131,6 +145,12 @@ struct Layout {
     const size_t cap = tailq_capacity(chunk * P::NMAT);
     const size_t cap_max = g_tail_cap_max.load();
     tail_cap = (uint32_t)(cap < cap_max ? cap : cap_max);
+  }
+  int carve(size_t chunk) {
+    uint8_t* b;
+    int rc = ws_reserve(need(chunk), &b);
+    if (rc) return rc;
+    place(b, chunk);
     return 0;
   }
 };
@@ -208,6 +228,7 @@ template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
+  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
@@ -242,6 +263,7 @@ template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
+  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   const bool shared = pk_stride == 0;
@@ -283,15 +305,10 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 
 // Decapsulation.  sk_stride == SKB: n keys (ref/kem.c:94-127 n times);
 // sk_stride == 0: n ciphertexts for ONE secret key, matrix expanded once.
+// the kernel sequence of a decapsulation over a workspace that is already laid out
 template <class P, bool N90>
-int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
-  const size_t gc = g_chunk.load();
-  const size_t chunk = n < gc ? n : gc;
+int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
   const bool shared = sk_stride == 0;
-  Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
   if (shared)
     if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
   const int16_t* mat = shared ? L.smat : L.mat;
@@ -326,6 +343,18 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
 }
 
 template <class P, bool N90>
+int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
+  WsUse use(st);
+  if (use.rc) return use.rc;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st);
+}
+
+template <class P, bool N90>
 int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
   if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
   if constexpr (N90) {
@@ -344,13 +373,17 @@ int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed,
 // are split/joined with strided device copies into stream-ordered temporaries.
 struct AsyncBuf {
   uint8_t* p = nullptr;
+  size_t bytes = 0;
   hipStream_t st = nullptr;
   ~AsyncBuf() {
-    if (p) (void)hipFreeAsync(p, st);
+    if (!p) return;
+    (void)hipMemsetAsync(p, 0, bytes, st);  // shared secrets and ephemeral coins pass through these temporaries
+    (void)hipFreeAsync(p, st);
   }
-  int alloc(size_t bytes, hipStream_t s) {
+  int alloc(size_t n, hipStream_t s) {
     st = s;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&p), bytes ? bytes : 16, s));
+    bytes = n ? n : 16;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&p), bytes, s));
     return 0;
   }
 };
@@ -554,6 +587,19 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
   HostCtx* ctx = nullptr;
   if (int rc = host_ctx(total, &ctx)) return rc;
   Streams& S = ctx->S;
+  // Every early return below leaves copies into or out of caller memory (and out
+  // of Coins' buffer) in flight: drain the three streams before the caller may
+  // free anything.  Disarmed after the final synchronisation of the normal path.
+  struct Drain {
+    Streams& S;
+    bool armed = true;
+    ~Drain() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(S.in);
+      (void)hipStreamSynchronize(S.comp);
+      (void)hipStreamSynchronize(S.out);
+    }
+  } drain{S};
   std::vector<uint8_t*> din[2], dout[2];
   uint8_t* cur = ctx->staging;
   for (int s = 0; s < 2; s++) {
@@ -588,10 +634,7 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
     HIP_TRY(hipEventRecord(S.in_done[s], S.in));
     HIP_TRY(hipStreamWaitEvent(S.comp, S.in_done[s], 0));
     if (c >= 2) HIP_TRY(hipStreamWaitEvent(S.comp, S.out_done[s], 0));  // slot's outputs drained
-    if (int rc = f(m, din[s].data(), dout[s].data(), S.comp)) {
-      (void)hipDeviceSynchronize();
-      return rc;
-    }
+    if (int rc = f(m, din[s].data(), dout[s].data(), S.comp)) return rc;
     HIP_TRY(hipEventRecord(S.comp_done[s], S.comp));
     HIP_TRY(hipStreamWaitEvent(S.out, S.comp_done[s], 0));
     for (size_t i = 0; i < outs.size(); i++)
@@ -601,6 +644,7 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
   HIP_TRY(hipStreamSynchronize(S.out));
   HIP_TRY(hipStreamSynchronize(S.comp));
   HIP_TRY(hipStreamSynchronize(S.in));
+  drain.armed = false;
   return 0;
 }
 
@@ -616,7 +660,7 @@ struct Coins {
     }
   }
   ~Coins() {
-    if (!own.empty()) memset(own.data(), 0, own.size());
+    if (!own.empty()) explicit_bzero(own.data(), own.size());  // not a dead store the compiler may drop
   }
 };
 
@@ -944,13 +988,17 @@ int kyber_hip_release(void) {
   if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
   if (g_ws[dev].base) {
     HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g_ws[dev].base, 0, g_ws[dev].bytes));  // sigma, r, m, Kbar, PRF bytes of the last call
     HIP_TRY(hipFree(g_ws[dev].base));
     if (g_ws[dev].idle) (void)hipEventDestroy(g_ws[dev].idle);
     g_ws[dev] = Workspace{};
   }
   if (HostCtx* c = g_host[dev]) {
     HIP_TRY(hipDeviceSynchronize());
-    if (c->staging) HIP_TRY(hipFree(c->staging));
+    if (c->staging) {
+      HIP_TRY(hipMemset(c->staging, 0, c->cap));  // secret keys and shared secrets were staged here
+      HIP_TRY(hipFree(c->staging));
+    }
     delete c;  // streams and events
     g_host[dev] = nullptr;
   }
@@ -991,10 +1039,11 @@ int kyber_hip_profile_read(char* buf, size_t len) {
   return 0;
 }
 
-// weak default entropy source; aborts like the reference's on OS failure (ref/randombytes.c:49-50)
+// weak default entropy source; retries on EINTR and aborts on any other OS failure like the reference's (ref/randombytes.c:46-50)
 __attribute__((weak)) void randombytes(uint8_t* out, size_t outlen) {
   while (outlen) {
     ssize_t r = getrandom(out, outlen > 256 ? 256 : outlen, 0);
+    if (r < 0 && errno == EINTR) continue;  // ref/randombytes.c:46-50
     if (r < 0) abort();
     out += r;
     outlen -= (size_t)r;

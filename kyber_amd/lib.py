@@ -118,6 +118,12 @@ def _torch_stream():
 def _tptr(t, nbytes, name):
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("%s must be a contiguous CUDA tensor" % name)
+    import torch
+    if t.device.index != torch.cuda.current_device():
+        # the library launches on the CURRENT device (workspace, locks, stream): a tensor of
+        # another device would hand its kernels a foreign pointer
+        raise ValueError("%s lives on cuda:%d but the current device is cuda:%d; use torch.cuda.device(...)"
+                         % (name, t.device.index, torch.cuda.current_device()))
     if t.numel() * t.element_size() != nbytes:
         raise ValueError("%s: expected %d bytes, got %d" % (name, nbytes, t.numel() * t.element_size()))
     if t.data_ptr() % 16:
@@ -203,6 +209,8 @@ class KyberHip:
         n = coins.numel() // 32
         ct = torch.empty((n, self.ct_bytes), dtype=torch.uint8, device=pk.device) if ct is None else ct
         ss = torch.empty((n, 32), dtype=torch.uint8, device=pk.device) if ss is None else ss
+        if n == 0:  # empty tensors have no data pointer; same result as the host path
+            return ct, ss
         _check(self.lib.kyber_batch_enc_shared_pk_dev(self.k, self.nineties, n, _tptr(ct, n * self.ct_bytes, "ct"),
                                                       _tptr(ss, n * 32, "ss"), _tptr(pk, self.pk_bytes, "pk"),
                                                       _tptr(coins, n * 32, "coins"), _torch_stream()),
@@ -213,6 +221,8 @@ class KyberHip:
         import torch
         n = ct.numel() // self.ct_bytes
         ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device) if ss is None else ss
+        if n == 0:
+            return ss
         _check(self.lib.kyber_batch_dec_shared_sk_dev(self.k, self.nineties, n, _tptr(ss, n * 32, "ss"),
                                                       _tptr(ct, n * self.ct_bytes, "ct"), _tptr(sk, self.sk_bytes, "sk"),
                                                       _torch_stream()), "kyber_batch_dec_shared_sk_dev")
@@ -223,6 +233,8 @@ class KyberHip:
         n = coins.numel() // 64
         pk = torch.empty((n, self.pk_bytes), dtype=torch.uint8, device=coins.device) if pk is None else pk
         sk = torch.empty((n, self.sk_bytes), dtype=torch.uint8, device=coins.device) if sk is None else sk
+        if n == 0:
+            return pk, sk
         _check(self.lib.kyber_batch_keypair_dev(self.k, self.nineties, n, _tptr(pk, n * self.pk_bytes, "pk"),
                                                 _tptr(sk, n * self.sk_bytes, "sk"), _tptr(coins, n * 64, "coins"),
                                                 _torch_stream()), "kyber_batch_keypair_dev")
@@ -233,6 +245,8 @@ class KyberHip:
         n = coins.numel() // 32
         ct = torch.empty((n, self.ct_bytes), dtype=torch.uint8, device=pk.device) if ct is None else ct
         ss = torch.empty((n, 32), dtype=torch.uint8, device=pk.device) if ss is None else ss
+        if n == 0:
+            return ct, ss
         _check(self.lib.kyber_batch_enc_dev(self.k, self.nineties, n, _tptr(ct, n * self.ct_bytes, "ct"),
                                             _tptr(ss, n * 32, "ss"), _tptr(pk, n * self.pk_bytes, "pk"),
                                             _tptr(coins, n * 32, "coins"), _torch_stream()), "kyber_batch_enc_dev")
@@ -242,6 +256,8 @@ class KyberHip:
         import torch
         n = ct.numel() // self.ct_bytes
         ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device) if ss is None else ss
+        if n == 0:
+            return ss
         _check(self.lib.kyber_batch_dec_dev(self.k, self.nineties, n, _tptr(ss, n * 32, "ss"),
                                             _tptr(ct, n * self.ct_bytes, "ct"), _tptr(sk, n * self.sk_bytes, "sk"),
                                             _torch_stream()), "kyber_batch_dec_dev")
@@ -252,6 +268,8 @@ class KyberHip:
         import torch
         n = seeds.numel() // 32
         mat = torch.empty((n, self.k * self.k, 256), dtype=torch.int16, device=seeds.device)
+        if n == 0:
+            return mat
         _check(self.lib.kyber_batch_gen_matrix_dev(self.k, self.nineties, n, _tptr(mat, mat.numel() * 2, "mat"),
                                                    _tptr(seeds, n * 32, "seeds"), int(bool(transposed)),
                                                    _torch_stream()), "kyber_batch_gen_matrix_dev")
