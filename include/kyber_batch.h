@@ -76,6 +76,24 @@ int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t *pk, uint8_t 
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, void *stream);
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
 
+/* ---- decapsulation that allocates nothing ----
+ * No counterpart in the reference (whose functions never allocate anyway).  It
+ * is for callers that cannot call hipMalloc: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation.  Same arguments,
+ * results and error codes as kyber_batch_dec_dev, but the internal workspace
+ * is a fixed device array inside the library (about 40 MB per GPU, held until
+ * the process ends) instead of a grow-on-demand allocation, so
+ *   - n is limited to KYBER_HIP_NOALLOC_MAX_N instances per call; a larger n
+ *     returns KYBER_HIP_EINVAL with a message in kyber_hip_last_error();
+ *   - the call makes no hipMalloc / hipFree / allocating library call
+ *     (with profiling off, see kyber_hip_profile_enable);
+ *   - all calls on one GPU share that one array: two calls whose GPU work
+ *     overlaps in time (different streams, no ordering between them) race.
+ *     Issue them on one stream, or order the streams yourself. */
+#define KYBER_HIP_NOALLOC_MAX_N 4096
+int kyber_batch_dec_dev_noalloc(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
+size_t kyber_hip_noalloc_max_n(void); /* = KYBER_HIP_NOALLOC_MAX_N of the library that is loaded */
+
 /* ---- server-shaped variants: one key, many operations ----
  * enc_shared_pk: n encapsulations to ONE public key `pk` (KYBER_PUBLICKEYBYTES
  * bytes), e.g. n clients' worth of ciphertexts for one static server key.

@@ -354,6 +354,44 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st);
 }
 
+// ---- decapsulation that allocates nothing (include/kyber_batch.h: kyber_batch_dec_dev_noalloc) ----
+// The workspace of kyber_batch_dec_dev (expanded matrices, PRF bytes, the
+// 128-byte records, the sampler's tail queue) is carved out of this file-scope
+// device array instead of a hipMalloc'ed block.  Every GPU the library runs
+// on holds its own copy until the process ends.  In host code the array's name
+// is only a handle: its device address is asked for once per device with
+// hipGetSymbolAddress and only that pointer is ever handed to kernels.
+constexpr size_t NOALLOC_MAX_N = KYBER_HIP_NOALLOC_MAX_N;
+constexpr size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+constexpr size_t NOALLOC_SCRATCH_BYTES =
+    max3(Layout<Par<2>>::need(NOALLOC_MAX_N), Layout<Par<3>>::need(NOALLOC_MAX_N), Layout<Par<4>>::need(NOALLOC_MAX_N));
+static __device__ __align__(256) uint8_t scratch[NOALLOC_SCRATCH_BYTES];
+uint8_t* g_scratch_ptr[MAX_DEV] = {};  // device address of `scratch` on each device, guarded by g_dev_mu[dev]
+
+template <class P, bool N90>
+int dec_noalloc(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
+  static_assert(Layout<P>::need(NOALLOC_MAX_N) <= NOALLOC_SCRATCH_BYTES, "scratch too small");
+  if (n > NOALLOC_MAX_N) {
+    snprintf(g_err, sizeof g_err, "kyber_batch_dec_dev_noalloc: n = %zu exceeds KYBER_HIP_NOALLOC_MAX_N = %zu", n, NOALLOC_MAX_N);
+    return KYBER_HIP_EINVAL;
+  }
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));  // this device's copy (dev is current)
+    if (!p) return KYBER_HIP_EHIP;
+    g_scratch_ptr[dev] = static_cast<uint8_t*>(p);
+  }
+  Layout<P> L;
+  L.place(g_scratch_ptr[dev], n);
+  // what must start at zero (the tail queue's counter) is cleared by sample_matrix
+  // on `st`; every other word of the workspace is written before it is read
+  return dec_run<P, N90>(n, n, L, ss, ct, sk, P::SKB, st);
+}
+
 template <class P, bool N90>
 int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
   if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
@@ -818,6 +856,14 @@ int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, dec_each_dev, n, ss, ct, sk, st);
 }
+int kyber_batch_dec_dev_noalloc(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
+  if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (k < 2 || k > 4 || (nineties != 0 && nineties != 1)) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, dec_noalloc, n, ss, ct, sk, st);
+}
+size_t kyber_hip_noalloc_max_n(void) { return NOALLOC_MAX_N; }
 int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;

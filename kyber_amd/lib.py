@@ -62,6 +62,7 @@ def library():
         "kyber_batch_keypair_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_enc_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
+        "kyber_batch_dec_dev_noalloc": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_enc_shared_pk": [ci, ci, sz, u8p, u8p, u8p, u8p],
         "kyber_batch_dec_shared_sk": [ci, ci, sz, u8p, u8p, u8p],
         "kyber_batch_enc_shared_pk_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
@@ -83,6 +84,7 @@ def library():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ctypes.c_int
+    lib.kyber_hip_noalloc_max_n.argtypes, lib.kyber_hip_noalloc_max_n.restype = [], ctypes.c_size_t
     for name in ("kyber_hip_pk_bytes", "kyber_hip_sk_bytes", "kyber_hip_ct_bytes"):
         fn = getattr(lib, name)
         fn.argtypes = [ctypes.c_int]
@@ -263,6 +265,17 @@ class KyberHip:
                                             _torch_stream()), "kyber_batch_dec_dev")
         return ss
 
+    def dec_dev_noalloc(self, ct, sk, ss):
+        """kyber_batch_dec_dev_noalloc: as dec_dev, but the library's workspace is its
+        fixed device array (no allocation anywhere; ss must be given; n <= noalloc_max_n())."""
+        n = ct.numel() // self.ct_bytes
+        if n == 0:
+            return ss
+        _check(self.lib.kyber_batch_dec_dev_noalloc(self.k, self.nineties, n, _tptr(ss, n * 32, "ss"),
+                                                    _tptr(ct, n * self.ct_bytes, "ct"), _tptr(sk, n * self.sk_bytes, "sk"),
+                                                    _torch_stream()), "kyber_batch_dec_dev_noalloc")
+        return ss
+
     def gen_matrix_dev(self, seeds, transposed):
         """seeds: uint8[n,32] CUDA tensor -> int16[n, k*k, 256] (ref/indcpa.c:164-192)."""
         import torch
@@ -290,6 +303,10 @@ def profile_read():
         name, cnt, ms = line.split()
         out[name] = (int(cnt), float(ms))
     return out
+
+
+def noalloc_max_n():
+    return int(library().kyber_hip_noalloc_max_n())
 
 
 def set_chunk(instances):

@@ -1,0 +1,58 @@
+"""GPU: kyber_batch_dec_dev_noalloc (the entry point that allocates nothing,
+include/kyber_batch.h) gives the same bytes as kyber_batch_dec_dev, on two
+calls in a row that share the library's fixed scratch array -- the second with
+a smaller batch -- for every parameter set; oversize batches are refused."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import kyber_amd
+from kyber_amd import lib as kl
+
+pytestmark = pytest.mark.gpu
+
+SETS = [(2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1)]
+
+
+def _instances(kem, n, seed, oracle):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = kem.keypair_dev(kc)
+    ct, ss = kem.enc_dev(pk, ec)
+    ct[::5, 3] ^= 0x40  # every fifth ciphertext is rejected (implicit rejection path, ref/kem.c:116-122)
+    return ct, sk
+
+
+@pytest.mark.parametrize("k,n90", SETS)
+def test_noalloc_matches_dec_dev_two_calls(k, n90, oracle):
+    kem = kyber_amd.KyberHip(k, n90)
+    nmax = kl.noalloc_max_n()
+    for call, n in enumerate((nmax, 777)):  # full scratch first, then a smaller batch over its leftovers
+        ct, sk = _instances(kem, n, 100 * k + n90 + call, oracle)
+        want = kem.dec_dev(ct, sk)
+        got = torch.full((n, 32), 0xA5, dtype=torch.uint8, device="cuda")
+        kem.dec_dev_noalloc(ct, sk, got)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), "call %d (n=%d) differs from kyber_batch_dec_dev" % (call, n)
+        idx = torch.arange(0, n, 97, device="cuda")
+        assert np.array_equal(got[idx].cpu().numpy(), oracle.dec(k, ct[idx].cpu().numpy(), sk[idx].cpu().numpy(), n90))
+
+
+def test_noalloc_rejects_oversize_and_bad_arguments():
+    kem = kyber_amd.KyberHip(3)
+    n = kl.noalloc_max_n() + 1
+    ct = torch.zeros((n, kem.ct_bytes), dtype=torch.uint8, device="cuda")
+    sk = torch.zeros((n, kem.sk_bytes), dtype=torch.uint8, device="cuda")
+    ss = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    with pytest.raises(kl.KyberHipError, match="KYBER_HIP_NOALLOC_MAX_N"):
+        kem.dec_dev_noalloc(ct, sk, ss)
+    L = kl.library()
+    assert L.kyber_batch_dec_dev_noalloc(3, 0, 1, None, ctypes.c_void_p(ct.data_ptr()), ctypes.c_void_p(sk.data_ptr()), None) == -1
+    assert L.kyber_batch_dec_dev_noalloc(5, 0, 1, ctypes.c_void_p(ss.data_ptr()), ctypes.c_void_p(ct.data_ptr()),
+                                         ctypes.c_void_p(sk.data_ptr()), None) == -1
+    assert L.kyber_batch_dec_dev_noalloc(3, 0, 0, ctypes.c_void_p(ss.data_ptr()), ctypes.c_void_p(ct.data_ptr()),
+                                         ctypes.c_void_p(sk.data_ptr()), None) == 0
