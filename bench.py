@@ -291,7 +291,8 @@ def launch_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():  # stdout carries the one JSON line; library chatter (e.g. "[Gloo] Rank 0 ...") goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 

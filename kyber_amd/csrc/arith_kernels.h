@@ -146,110 +146,155 @@ __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restri
 // ref/indcpa.c:268-295.  CMP = false: write the ciphertext.  CMP = true
 // (decapsulation's re-encryption, ref/kem.c:114-116): compare with the given
 // ciphertext instead and raise the instance's fail flag on any difference.
+//
+// One 32-lane group owns one instance from start to end: it transforms the K
+// noise polynomials r_j once and keeps r^ in registers as cached multiplicands
+// (fpoly.h FCache: converted, twisted and summed once instead of once per
+// matrix row), then produces the K+1 result rows u_0..u_{K-1}, v one after the
+// other.  Nothing is shared between groups before the ciphertext tile, so the
+// only workgroup barrier is the one in front of the final copy-out.
+template <int K>
+struct FcGroups {  // polynomials that share one unreduced accumulation (at most three, fpoly.h)
+  static constexpr int N = (K + 2) / 3;
+  static constexpr int begin(int g) { return g * K / N; }
+  static constexpr int end(int g) { return (g + 1) * K / N; }
+};
+
 template <class P, bool CMP>
-__global__ void __launch_bounds__(256) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
+__global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
                                                    uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
                                                    size_t mat_stride,  // int16 per instance; 0 = one matrix for all
                                                    const uint8_t* __restrict__ prf, uint8_t* __restrict__ ct) {
   constexpr int K = P::K, NJ = 2 * K + 1;
-  __shared__ __attribute__((aligned(16))) int16_t sp[G_INST][K][256];
+  using G = FcGroups<K>;
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
   __shared__ uint32_t bad[G_INST];
   __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
+  const int li = w.g;                       // G_INST == number of groups
+  const int gi = min(inst0 + li, n - 1);    // surplus groups of the last workgroup recompute the last instance
   f_twiddles_to_lds(ztab);
   if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
 
-  // Global operands are fetched one loop iteration ahead of their use: each
-  // iteration's dependent chain (LDS transposes inside the transforms) is long
-  // enough to hide an HBM round trip that would otherwise be paid in full at
-  // 3-4 waves per SIMD.
+  const uint8_t* prf_i = prf + (size_t)gi * NJ * P::PRF_STRIDE;
+  const int16_t* mat_i = mat + (size_t)gi * mat_stride;
+  const uint8_t* pk_i = pk + (size_t)gi * pk_stride;
 
-  // r^ = NTT(CBD_eta1(PRF(r, j)))
-  {
-    auto fetch = [&](int q, uint32_t (&r)[3]) {
-      const int li = q / K, j = q % K;
-      const int gi = min(inst0 + li, n - 1);
-      const uint8_t* b = prf + ((size_t)gi * NJ + j) * P::PRF_STRIDE;
-      if constexpr (P::ETA1 == 2) {
-        r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+  // Global operands are fetched one step ahead of their use (the transforms'
+  // dependent chains hide an HBM round trip that 3-4 waves per SIMD would not).
+  struct Ops {
+    uint4 a[K];           // matrix row entries (8 int16) or 12 key bytes in x,y,z
+    uint32_t noise, msg;  // PRF word for CBD2; message byte (row K only)
+  };
+  auto fetch_row = [&](int i, Ops& o) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (i < K) {
+        o.a[j] = *reinterpret_cast<const uint4*>(mat_i + (i * K + j) * 256 + 8 * w.t);
       } else {
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
-        r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+        const uint32_t* sb = reinterpret_cast<const uint32_t*>(pk_i + 384 * j) + 3 * w.t;
+        o.a[j] = make_uint4(sb[0], sb[1], sb[2], 0u);
       }
-    };
-    uint32_t nxt[3] = {0, 0, 0};
-    fetch(w.g, nxt);
-    for (int q = w.g; q < G_INST * K; q += 8) {
-      const int li = q / K, j = q % K;
-      uint32_t cur[3] = {nxt[0], nxt[1], nxt[2]};
-      if (q + 8 < G_INST * K) fetch(q + 8, nxt);
+    }
+    o.noise = *reinterpret_cast<const uint32_t*>(prf_i + (size_t)(K + i) * P::PRF_STRIDE + 4 * w.t);  // nonce K+i
+    o.msg = (i == K) ? small[(size_t)gi * SMALL + w.t] : 0u;
+  };
+  auto fetch_noise1 = [&](int j, uint32_t (&r)[3]) {
+    const uint8_t* b = prf_i + (size_t)j * P::PRF_STRIDE;
+    if constexpr (P::ETA1 == 2) {
+      r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+    } else {
+      const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
+      r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+    }
+  };
+
+  // r^_j = NTT(CBD_eta1(PRF(r, j))), cached
+  FCache rc[K];
+  float corr[G::N][8];
+  Ops nxt;
+  {
+    uint32_t nw[K][3];
+#pragma unroll
+    for (int j = 0; j < K; j++) fetch_noise1(j, nw[j]);
+    fetch_row(0, nxt);
+#pragma unroll
+    for (int j = 0; j < K; j++) {
       int c[8];
       float f[8];
-      if constexpr (P::ETA1 == 2) cbd2_word(cur[0], c);
-      else cbd3_words(cur[0] | (cur[1] & 0xFFu) << 16, (cur[1] >> 8) | cur[2] << 8, c);
-      i2f8(c, f);
+      if constexpr (P::ETA1 == 2) cbd2_word(nw[j][0], c);
+      else cbd3_words(nw[j][0] | (nw[j][1] & 0xFFu) << 16, (nw[j][1] >> 8) | nw[j][2] << 8, c);
+      // r is scaled by 128^-1 here (|.| <= 78), once per polynomial, so that the K+1 inverse
+      // transforms below need no final scaling: invntt is linear in r^
+#pragma unroll
+      for (int k = 0; k < 8; k++) f[k] = (float)c[k] * KY_NINV_PLAIN;
       f_ntt_fwd(wk[w.g], ztab, w.t, f);
-      f_put_i16(sp[li][j], w.t, f);
+      f_cache_make(rc[j], f, ztab, w.t);
+    }
+#pragma unroll
+    for (int g = 0; g < G::N; g++) {
+      float S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = G::begin(g); j < G::end(g); j++) f_cache_sum(S, rc[j]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) corr[g][k] = f_corr(S[k]);
     }
   }
-  __syncthreads();
+
   // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
-  {
-    struct Ops {
-      uint4 a[K];          // matrix row entries (8 int16) or 12 key bytes in x,y,z
-      uint32_t noise, msg; // PRF word for CBD2; message byte (row K only)
-    };
-    auto fetch = [&](int q, Ops& o) {
-      const int li = q / (K + 1), i = q % (K + 1);
-      const int gi = min(inst0 + li, n - 1);
+#pragma unroll 1
+  for (int i = 0; i <= K; i++) {
+    const Ops cur = nxt;
+    if (i < K) fetch_row(i + 1, nxt);
+    float acc[8];
+    if (i < K) {
+      // canonical matrix entries against the offset-corrected start value
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (i < K) {
-          o.a[j] = *reinterpret_cast<const uint4*>(mat + (size_t)gi * mat_stride + (i * K + j) * 256 + 8 * w.t);
-        } else {
-          const uint32_t* sb = reinterpret_cast<const uint32_t*>(pk + (size_t)gi * pk_stride + 384 * j) + 3 * w.t;
-          o.a[j] = make_uint4(sb[0], sb[1], sb[2], 0u);
+      for (int g = 0; g < G::N; g++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (g == 0) ? corr[0][k] : fred(acc[k]) + corr[g][k];
+#pragma unroll
+        for (int j = G::begin(g); j < G::end(g); j++) {
+          float a[8];
+          u16x8_to_f(cur.a[j], a);
+          f_mac(acc, a, rc[j]);
         }
       }
-      o.noise = *reinterpret_cast<const uint32_t*>(prf + ((size_t)gi * NJ + K + i) * P::PRF_STRIDE + 4 * w.t);  // nonce K+i
-      o.msg = (i == K) ? small[(size_t)gi * SMALL + w.t] : 0u;
-    };
-    Ops nxt;
-    fetch(w.g, nxt);
-    for (int q = w.g; q < G_INST * (K + 1); q += 8) {
-      const int li = q / (K + 1), i = q % (K + 1);
-      Ops cur = nxt;
-      if (q + 8 < G_INST * (K + 1)) fetch(q + 8, nxt);
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    } else {
+      // key bytes carry any 12-bit value (ref/poly.c:142-143): centre them first
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        int ai[8];
-        if (i < K) unpack8(cur.a[j], ai);
-        else frombytes12(cur.a[j].x, cur.a[j].y, cur.a[j].z, ai);
-        i2f8(ai, a);
-        f_get_i16(sp[li][j], w.t, b);
-        f_basemul_acc(acc, a, b, ztab, w.t);
+      for (int g = 0; g < G::N; g++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (g == 0) ? 0.0f : fred(acc[k]);
+#pragma unroll
+        for (int j = G::begin(g); j < G::end(g); j++) {
+          int ai[8];
+          float a[8];
+          frombytes12(cur.a[j].x, cur.a[j].y, cur.a[j].z, ai);
+#pragma unroll
+          for (int k = 0; k < 8; k++) a[k] = fred((float)ai[k]);
+          f_mac(acc, a, rc[j]);
+        }
       }
+    }
 #pragma unroll
-      for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
-      f_ntt_inv(wk[w.g], ztab, w.t, acc);
-      int e[8];
-      unsigned c[8];
-      cbd2_word(cur.noise, e);
-      if (i < K) {
+    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+    f_ntt_inv<false>(wk[w.g], ztab, w.t, acc);  // |acc| <= 3330
+    int e[8];
+    unsigned c[8];
+    cbd2_word(cur.noise, e);
+    if (i < K) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = fcompress<P::DU>(acc[k] + (float)e[k]);  // |.| <= 1668 + 2
-        pack_bits_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
-      } else {
-        int m[8];
-        frommsg_contig(cur.msg, m);
+      for (int k = 0; k < 8; k++) c[k] = fcompress<P::DU>(acc[k] + (float)e[k]);  // |.| <= 3330 + 2
+      pack_bits_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
+    } else {
+      int m[8];
+      frommsg_contig(cur.msg, m);
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = fcompress<P::DV>(acc[k] + (float)(e[k] + m[k]));  // |.| <= 1668 + 2 + 1665
-        pack_bits_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
-      }
+      for (int k = 0; k < 8; k++) c[k] = fcompress<P::DV>(acc[k] + (float)(e[k] + m[k]));  // |.| <= 3330 + 2 + 1665 = 4997 <= 5000 (fcompress)
+      pack_bits_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
     }
   }
   __syncthreads();

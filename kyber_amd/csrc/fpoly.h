@@ -185,6 +185,10 @@ __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float
 //      2^-16 and 2^16 cancel in the reference, ref/ntt.c:106-126)
 // bounds: sums double per layer and are reduced every second layer, so a
 // difference entering a product is <= 2 * 3336 = 6672 (11.2 M).
+// SCALE = false leaves out the final multiplication by 128^-1 (the caller has
+// folded it into a linear factor upstream, e.g. into r^): outputs are then
+// |c| <= 3330 (sums of two reduced values) instead of <= 1665.
+template <bool SCALE = true>
 __device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float (&c)[8]) {
   {
     float z0 = Z[127 - 2 * t], z1 = Z[126 - 2 * t];
@@ -219,8 +223,10 @@ __device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float
   c[0] = fred(c[0]); c[1] = fred(c[1]); c[4] = fred(c[4]); c[5] = fred(c[5]);
 #pragma unroll
   for (int m = 0; m < 4; m++) f_gs(c[m], c[m + 4], ZETAF[1]);
+  if constexpr (SCALE) {
 #pragma unroll
-  for (int m = 0; m < 8; m++) c[m] = fmm(c[m], KY_NINV_PLAIN);  // |c| <= 3336, * 26
+    for (int m = 0; m < 8; m++) c[m] = fmm(c[m], KY_NINV_PLAIN);  // |c| <= 3336, * 26
+  }
   KY_WSYNC();
   f_put_stride(p, t, c);
   KY_WSYNC();
@@ -243,6 +249,70 @@ __device__ __forceinline__ void f_basemul_acc(float (&acc)[8], const float (&a)[
     acc[o + 2] += fred(__builtin_fmaf(h1, -z, a[o + 2] * b[o + 2]));
     acc[o + 3] += fred(__builtin_fmaf(a[o + 2], b[o + 3], a[o + 3] * b[o + 2]));
   }
+}
+
+// ---------------------------------------------------------------- cached multiplicand
+// A polynomial b (NTT domain, centred, |b| <= 1665) that multiplies several
+// others -- r^ against the K+1 rows of encryption, s^ against the K rows of
+// key generation -- is kept per work-item as its 8 coefficients plus the four
+// "twisted" odd ones zb[p] = (+-zeta) * b[2p+1] mod q.  A base multiplication is
+// then pure multiply-add (ref/ntt.c:139-146 with the zeta product hoisted):
+//     c[2p]   += a[2p] * b[2p]   + a[2p+1] * zb[p]
+//     c[2p+1] += a[2p] * b[2p+1] + a[2p+1] * b[2p]
+// four FMAs per coefficient pair instead of five modular products, and the
+// sums over j stay UNREDUCED, which is exact while they stay below 2^24:
+//   * operands centred, |a| <= 1665 (f_mac after fred): six products <= 16.64 M.
+//   * matrix entries are canonical, a in [0, 3328].  Write a = a' + 1664 with
+//     |a'| <= 1664: sum a*b = sum a'*b + 1664*S, S = sum of the b-side factors
+//     (known once b is known, the same for every row).  The accumulator starts
+//     at corr = -q * rne(1664*S / q), a multiple of q within 1665 of -1664*S, so
+//     every partial sum  corr + sum_{first t} a*b  =  sum_{first t} a'*b
+//     - 1664*sum_{rest} b + (corr + 1664*S)  is bounded by 1664*1665*T + 1665
+//     for T products in all: T = 6 -> 16.63 M < 2^24 = 16.78 M.  The result is
+//     congruent to sum a*b and costs nothing per row.
+// So at most three polynomials (six products per coefficient) share one
+// accumulation; Kyber1024 splits its four into two groups (FC_GROUP).
+struct FCache {
+  float b[8], zb[4];
+};
+__device__ __forceinline__ void f_cache_make(FCache& c, const float (&b)[8], const float* Z, int t) {
+  const float z0 = Z[64 + 2 * t], z1 = Z[65 + 2 * t];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c.b[k] = b[k];
+  c.zb[0] = fmm(z0, b[1]);
+  c.zb[1] = fmm(-z0, b[3]);
+  c.zb[2] = fmm(z1, b[5]);
+  c.zb[3] = fmm(-z1, b[7]);
+}
+// S[] += the b-side factor sums of one cached polynomial
+__device__ __forceinline__ void f_cache_sum(float (&S)[8], const FCache& c) {
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    S[2 * p] += c.b[2 * p] + c.zb[p];
+    S[2 * p + 1] += c.b[2 * p + 1] + c.b[2 * p];
+  }
+}
+constexpr float FC_OFFSET = 1664.0f;
+// accumulator start value for canonical a (see above); |S| <= 6 * 1665
+__device__ __forceinline__ float f_corr(float S) {
+  const float x = FC_OFFSET * S;  // exact, < 2^24
+  const float k = __builtin_fmaf(x, QINVF, RND_MAGIC) - RND_MAGIC;
+  return -QF * k;
+}
+// acc[] += a[] o c, no reduction
+__device__ __forceinline__ void f_mac(float (&acc)[8], const float (&a)[8], const FCache& c) {
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    acc[2 * p] = __builtin_fmaf(a[2 * p], c.b[2 * p], __builtin_fmaf(a[2 * p + 1], c.zb[p], acc[2 * p]));
+    acc[2 * p + 1] = __builtin_fmaf(a[2 * p], c.b[2 * p + 1], __builtin_fmaf(a[2 * p + 1], c.b[2 * p], acc[2 * p + 1]));
+  }
+}
+// 8 packed unsigned 16-bit values -> fp32 (one v_cvt_f32_u32 with a sub-dword select each)
+__device__ __forceinline__ void u16x8_to_f(uint4 v, float (&f)[8]) {
+  f[0] = (float)(v.x & 0xFFFFu); f[1] = (float)(v.x >> 16);
+  f[2] = (float)(v.y & 0xFFFFu); f[3] = (float)(v.y >> 16);
+  f[4] = (float)(v.z & 0xFFFFu); f[5] = (float)(v.z >> 16);
+  f[6] = (float)(v.w & 0xFFFFu); f[7] = (float)(v.w >> 16);
 }
 
 // compact persistent storage: centred residues as int16, CONTIG access only

@@ -269,8 +269,20 @@ __device__ __forceinline__ void pack_bits_contig(uint8_t* out, int t, const unsi
     if (pos + D > 64) hi |= (pos >= 64) ? x << (pos - 64) : x >> (64 - pos);
   }
   uint8_t* o = out + D * t;
+  // widest stores the alignment of out + D*t allows (`out` is 4-byte aligned):
+  // ten single-byte LDS stores per work-item were the kernel's bank-conflict source
+  if constexpr (D % 4 == 0) {
 #pragma unroll
-  for (int b = 0; b < D; b++) o[b] = (uint8_t)(b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8)));
+    for (int b = 0; b < D; b += 4)
+      *reinterpret_cast<uint32_t*>(o + b) = (uint32_t)(b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8)));
+  } else if constexpr (D % 2 == 0) {
+#pragma unroll
+    for (int b = 0; b < D; b += 2)
+      *reinterpret_cast<uint16_t*>(o + b) = (uint16_t)(b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8)));
+  } else {
+#pragma unroll
+    for (int b = 0; b < D; b++) o[b] = (uint8_t)(b < 8 ? lo >> (8 * b) : hi >> (8 * (b - 8)));
+  }
 }
 template <int D>
 __device__ __forceinline__ void compress_contig(uint8_t* out, int t, const int (&c)[8]) {

@@ -53,6 +53,14 @@ def library():
         raise KyberHipError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # torch ships its own copy of the HIP/HSA runtime.  Whichever copy a process
+    # loads first must serve both: with the system runtime (this library's
+    # dependency) loaded first, torch's own then finds no device.  So let torch,
+    # where it is installed, load its runtime before the library is opened.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     u8p, i16p, sz, vp, ci = (ctypes.c_void_p,) * 2 + (ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int)
     sig = {
