@@ -48,97 +48,116 @@ __device__ __forceinline__ void st_bytes12(uint8_t* p, int t, const int (&c)[8])
 // ------------------------------------------------------------------ keypair arithmetic
 // ref/indcpa.c:220-238: s,e <- CBD(PRF); s^,e^ = NTT; t^ = A s^ + e^;
 // pk = tobytes(t^) || rho ; sk = tobytes(s^) (|| pk copy, ref/kem.c:28-29)
+// Same shape as k_enc_arith: a 32-lane group owns one instance, s^ stays in
+// registers as cached multiplicands for the K matrix rows, e^ waits in LDS.
+template <int K>
+struct FcGroups {  // polynomials that share one unreduced accumulation (at most three, fpoly.h)
+  static constexpr int N = (K + 2) / 3;
+  static constexpr int begin(int g) { return g * K / N; }
+  static constexpr int end(int g) { return (g + 1) * K / N; }
+};
+
 template <class P>
-__global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
-                                                  const uint8_t* __restrict__ prf, uint8_t* __restrict__ pk,
-                                                  uint8_t* __restrict__ sk) {
+__global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_kp_arith(int n, const uint8_t* __restrict__ small,
+                                                                      const int16_t* __restrict__ mat,
+                                                                      const uint8_t* __restrict__ prf, uint8_t* __restrict__ pk,
+                                                                      uint8_t* __restrict__ sk) {
   constexpr int K = P::K;
-  __shared__ __attribute__((aligned(16))) int16_t se[G_INST][2 * K][256];  // s^ then e^
+  using G = FcGroups<K>;
+  __shared__ __attribute__((aligned(16))) float eh[G_INST][K][256];  // e^, read back CONTIG only
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
+  const int li = w.g;
+  const int gi = min(inst0 + li, n - 1);
+  const bool live = inst0 + li < n;
   f_twiddles_to_lds(ztab);
 
-  // global operands are fetched one iteration ahead, as in k_enc_arith
+  const uint8_t* prf_i = prf + (size_t)gi * 2 * K * P::PRF_STRIDE;
+  const int16_t* mat_i = mat + (size_t)gi * P::NMAT * 256;
+  uint8_t* pk_i = pk + (size_t)gi * P::PKB;
+  uint8_t* sk_i = sk + (size_t)gi * P::SKB;
+
+  auto fetch_noise = [&](int v, uint32_t (&r)[3]) {
+    const uint8_t* b = prf_i + (size_t)v * P::PRF_STRIDE;
+    if constexpr (P::ETA1 == 2) {
+      r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
+    } else {
+      const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
+      r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
+    }
+  };
+  auto fetch_row = [&](int i, uint4 (&a)[K]) {
+#pragma unroll
+    for (int j = 0; j < K; j++) a[j] = *reinterpret_cast<const uint4*>(mat_i + (i * K + j) * 256 + 8 * w.t);
+  };
+
+  FCache sc[K];
+  float corr[G::N][8];
+  uint4 nxt[K];
   {
-    auto fetch = [&](int q, uint32_t (&r)[3]) {
-      const int li = q / (2 * K), v = q % (2 * K);
-      const int gi = min(inst0 + li, n - 1);
-      const uint8_t* b = prf + ((size_t)gi * 2 * K + v) * P::PRF_STRIDE;
-      if constexpr (P::ETA1 == 2) {
-        r[0] = *reinterpret_cast<const uint32_t*>(b + 4 * w.t);
-      } else {
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(b + 6 * w.t);
-        r[0] = h[0]; r[1] = h[1]; r[2] = h[2];
-      }
-    };
-    uint32_t nxt[3] = {0, 0, 0};
-    fetch(w.g, nxt);
-    for (int q = w.g; q < G_INST * 2 * K; q += 8) {
-      const int li = q / (2 * K), v = q % (2 * K);
-      const int gi = min(inst0 + li, n - 1);
-      const uint32_t cur[3] = {nxt[0], nxt[1], nxt[2]};
-      if (q + 8 < G_INST * 2 * K) fetch(q + 8, nxt);
+    uint32_t nw[2 * K][3];
+#pragma unroll
+    for (int v = 0; v < 2 * K; v++) fetch_noise(v, nw[v]);
+    fetch_row(0, nxt);
+#pragma unroll
+    for (int v = 0; v < 2 * K; v++) {
       int c[8];
       float f[8];
-      if constexpr (P::ETA1 == 2) cbd2_word(cur[0], c);
-      else cbd3_words(cur[0] | (cur[1] & 0xFFu) << 16, (cur[1] >> 8) | cur[2] << 8, c);
+      if constexpr (P::ETA1 == 2) cbd2_word(nw[v][0], c);
+      else cbd3_words(nw[v][0] | (nw[v][1] & 0xFFu) << 16, (nw[v][1] >> 8) | nw[v][2] << 8, c);
       i2f8(c, f);
-      f_ntt_fwd(wk[w.g], ztab, w.t, f);
-      f_put_i16(se[li][v], w.t, f);
-      if (v < K && inst0 + li < n) {  // sk = tobytes(s^)
-        f2canon8(f, c);
-        st_bytes12(sk + (size_t)gi * P::SKB + 384 * v, w.t, c);
+      f_ntt_fwd<true>(wk[w.g], ztab, w.t, f);
+      if (v < K) {
+        f_cache_make(sc[v], f, ztab, w.t);
+        f2canon8(f, c);  // sk = tobytes(s^)
+        if (live) st_bytes12(sk_i + 384 * v, w.t, c);
+      } else {
+        f_put_plain(eh[li][v - K], w.t, f);
       }
     }
+#pragma unroll
+    for (int g = 0; g < G::N; g++) {
+      float S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = G::begin(g); j < G::end(g); j++) f_cache_sum(S, sc[j]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) corr[g][k] = f_corr(S[k]);
+    }
   }
-  __syncthreads();
-  {
-    auto fetch = [&](int q, uint4 (&a)[K]) {
-      const int li = q / K, i = q % K;
-      const int gi = min(inst0 + li, n - 1);
+#pragma unroll 1
+  for (int i = 0; i < K; i++) {
+    uint4 cur[K];
 #pragma unroll
-      for (int j = 0; j < K; j++)
-        a[j] = *reinterpret_cast<const uint4*>(mat + ((size_t)gi * P::NMAT + i * K + j) * 256 + 8 * w.t);
-    };
-    uint4 nxt[K];
-    fetch(w.g, nxt);
-    for (int q = w.g; q < G_INST * K; q += 8) {
-      const int li = q / K, i = q % K;
-      const int gi = min(inst0 + li, n - 1);
-      uint4 cur[K];
+    for (int j = 0; j < K; j++) cur[j] = nxt[j];
+    if (i + 1 < K) fetch_row(i + 1, nxt);
+    float acc[8], e[8];
 #pragma unroll
-      for (int j = 0; j < K; j++) cur[j] = nxt[j];
-      if (q + 8 < G_INST * K) fetch(q + 8, nxt);
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    for (int g = 0; g < G::N; g++) {
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        int ai[8];
-        unpack8(cur[j], ai);
-        i2f8(ai, a);
-        f_get_i16(se[li][j], w.t, b);
-        f_basemul_acc(acc, a, b, ztab, w.t);
+      for (int k = 0; k < 8; k++) acc[k] = (g == 0) ? corr[0][k] : fred(acc[k]) + corr[g][k];
+#pragma unroll
+      for (int j = G::begin(g); j < G::end(g); j++) {
+        float a[8];
+        u16x8_to_f(cur[j], a);
+        f_mac(acc, a, sc[j]);
       }
-      f_get_i16(se[li][K + i], w.t, b);
-      int c[8];
+    }
+    f_get_plain(eh[li][i], w.t, e);  // written by this work-item itself
+    int c[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) c[k] = fcanon(fred(acc[k] + b[k]));  // + e^   ref/indcpa.c:234-235
-      if (inst0 + li < n) {
-        st_bytes12(pk + (size_t)gi * P::PKB + 384 * i, w.t, c);
-        st_bytes12(sk + (size_t)gi * P::SKB + P::PVB + 384 * i, w.t, c);
-      }
+    for (int k = 0; k < 8; k++) c[k] = fcanon(fred(fred(acc[k]) + e[k]));  // + e^   ref/indcpa.c:234-235
+    if (live) {
+      st_bytes12(pk_i + 384 * i, w.t, c);
+      st_bytes12(sk_i + P::PVB + 384 * i, w.t, c);
     }
   }
   // rho -> pk tail and its copy inside sk
-  if (threadIdx.x < G_INST * 8) {
-    const int li = threadIdx.x >> 3, wd = threadIdx.x & 7;
-    if (inst0 + li < n) {
-      const size_t gi = inst0 + li;
-      uint32_t r = reinterpret_cast<const uint32_t*>(small + gi * SMALL)[wd];
-      reinterpret_cast<uint32_t*>(pk + gi * P::PKB + P::PVB)[wd] = r;
-      reinterpret_cast<uint32_t*>(sk + gi * P::SKB + 2 * P::PVB)[wd] = r;
-    }
+  if (live && w.t < 8) {
+    uint32_t r = reinterpret_cast<const uint32_t*>(small + (size_t)gi * SMALL)[w.t];
+    reinterpret_cast<uint32_t*>(pk_i + P::PVB)[w.t] = r;
+    reinterpret_cast<uint32_t*>(sk_i + 2 * P::PVB)[w.t] = r;
   }
 }
 
@@ -153,13 +172,6 @@ __global__ void __launch_bounds__(256) k_kp_arith(int n, const uint8_t* __restri
 // matrix row), then produces the K+1 result rows u_0..u_{K-1}, v one after the
 // other.  Nothing is shared between groups before the ciphertext tile, so the
 // only workgroup barrier is the one in front of the final copy-out.
-template <int K>
-struct FcGroups {  // polynomials that share one unreduced accumulation (at most three, fpoly.h)
-  static constexpr int N = (K + 2) / 3;
-  static constexpr int begin(int g) { return g * K / N; }
-  static constexpr int end(int g) { return (g + 1) * K / N; }
-};
-
 template <class P, bool CMP>
 __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, const uint8_t* __restrict__ pk, size_t pk_stride,
                                                    uint8_t* __restrict__ small, const int16_t* __restrict__ mat,
@@ -230,7 +242,7 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
       // transforms below need no final scaling: invntt is linear in r^
 #pragma unroll
       for (int k = 0; k < 8; k++) f[k] = (float)c[k] * KY_NINV_PLAIN;
-      f_ntt_fwd(wk[w.g], ztab, w.t, f);
+      f_ntt_fwd<true>(wk[w.g], ztab, w.t, f);
       f_cache_make(rc[j], f, ztab, w.t);
     }
 #pragma unroll
@@ -246,8 +258,7 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
   // rows 0..K-1: u_i = invntt(At_i . r^) + e1_i ; row K: v = invntt(t^ . r^) + e2 + msg
 #pragma unroll 1
   for (int i = 0; i <= K; i++) {
-    const Ops cur = nxt;
-    if (i < K) fetch_row(i + 1, nxt);
+    Ops& cur = nxt;  // consumed by the multiply-adds, then refilled for the next row while this row is transformed
     float acc[8];
     if (i < K) {
       // canonical matrix entries against the offset-corrected start value
@@ -279,19 +290,21 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
         }
       }
     }
+    const uint32_t noise = cur.noise, msg = cur.msg;
+    if (i < K) fetch_row(i + 1, nxt);
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
     f_ntt_inv<false>(wk[w.g], ztab, w.t, acc);  // |acc| <= 3330
     int e[8];
     unsigned c[8];
-    cbd2_word(cur.noise, e);
+    cbd2_word(noise, e);
     if (i < K) {
 #pragma unroll
       for (int k = 0; k < 8; k++) c[k] = fcompress<P::DU>(acc[k] + (float)e[k]);  // |.| <= 3330 + 2
       pack_bits_contig<P::DU>(ctb[li] + P::UB * i, w.t, c);
     } else {
       int m[8];
-      frommsg_contig(cur.msg, m);
+      frommsg_contig(msg, m);
 #pragma unroll
       for (int k = 0; k < 8; k++) c[k] = fcompress<P::DV>(acc[k] + (float)(e[k] + m[k]));  // |.| <= 3330 + 2 + 1665 = 4997 <= 5000 (fcompress)
       pack_bits_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
@@ -385,24 +398,49 @@ __device__ __forceinline__ uint4 ld_poly16(const int16_t* base, long pi, int t) 
 }
 __device__ __forceinline__ void st_poly16(int16_t* base, long pi, int t, const int (&c)[8]) { lds_put_contig(base + pi * 256, t, c); }
 
+// Forward transform on the fp32 engine: poly_ntt's output is the Barrett-centred
+// representative (ref/poly.c:244-248, ref/reduce.c:35-42), which depends on the
+// residue only, and fred() of a value this small returns exactly that
+// representative.  Inputs are any int16 the reference's int16 arithmetic can
+// take without overflow; a wavefront that sees a coefficient beyond the
+// engine's entry bound (4095) centres its inputs first.
+// The loop is unrolled by two over a ping-pong pair of load registers: with a
+// rotating queue (q[d] = q[d+1]) the register copies made the compiler wait for
+// every outstanding load and store at the top of each iteration (vmcnt(0)), so
+// nothing was ever in flight behind the transform.
 __global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
-  __shared__ __attribute__((aligned(16))) int16_t wk[8][256];
-  __shared__ int ztab[128];
+  __shared__ __attribute__((aligned(16))) float wk[8][256];
+  __shared__ float ztab[128];
   const Grp w = grp();
-  twiddles_to_lds(ztab);
+  f_twiddles_to_lds(ztab);
   const long stride = (long)gridDim.x * 8;
   long pi = (long)blockIdx.x * 8 + w.g;
-  uint4 nxt = make_uint4(0, 0, 0, 0);
-  if (pi < npoly) nxt = ld_poly16(r, pi, w.t);
-  for (; pi < npoly; pi += stride) {
-    const uint4 cur = nxt;
-    if (pi + stride < npoly) nxt = ld_poly16(r, pi + stride, w.t);
-    int c[8];
-    KY_GSYNC();  // the group's previous transform has left wk
-    *reinterpret_cast<uint4*>(wk[w.g] + 8 * w.t) = cur;
-    KY_GSYNC();
-    ntt_fwd(wk[w.g], ztab, w.t, c);
-    st_poly16(r, pi, w.t, c);
+  auto transform = [&](const uint4& in, long at) {
+    float f[8];
+    s16x8_to_f(in, f);
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+                            fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+    if (__any(big > 4095.0f)) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) f[k] = fred(f[k]);
+    }
+    f_ntt_fwd(wk[w.g], ztab, w.t, f);
+    *reinterpret_cast<uint4*>(r + at * 256 + 8 * w.t) = f_to_s16x8(f);
+  };
+  // loads are unconditional (index clamped, surplus data unused): a load under a branch makes
+  // the number of operations in flight path-dependent and the compiler falls back to vmcnt(0)
+  const long last = npoly - 1;
+  if (pi > last) return;
+  uint4 a = ld_poly16(r, pi, w.t), b;
+  while (true) {
+    b = ld_poly16(r, min(pi + stride, last), w.t);
+    transform(a, pi);
+    pi += stride;
+    if (pi > last) break;
+    a = ld_poly16(r, min(pi + stride, last), w.t);
+    transform(b, pi);
+    pi += stride;
+    if (pi > last) break;
   }
 }
 

@@ -137,6 +137,11 @@ __device__ __forceinline__ void f_gs(float& a, float& b, float z) {  // Gentlema
 // bounds: each layer adds <= 1668, so 4095 -> 9099 after three layers (products
 // <= 1664 * 7431 = 12.4 M); reduce; 1668 -> 6672 after three more (products
 // <= 8.4 M); last layer multiplies values <= 6672 (11.2 M).
+// SMALL_IN: |c| <= 78 on entry (noise polynomials, also scaled by 128^-1 = -26).
+// Values then stay <= 78 + 6 * 1665 = 10068 up to the last layer, whose products
+// are <= 1664 * 10068 = 16.75 M < 2^24, so the reduction after the third layer
+// is left out.
+template <bool SMALL_IN = false>
 __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float (&c)[8]) {
   KY_WSYNC();
   f_put_contig(p, t, c);
@@ -148,8 +153,10 @@ __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float
   f_ct(c[4], c[6], ZETAF[3]); f_ct(c[5], c[7], ZETAF[3]);
   f_ct(c[0], c[1], ZETAF[4]); f_ct(c[2], c[3], ZETAF[5]);
   f_ct(c[4], c[5], ZETAF[6]); f_ct(c[6], c[7], ZETAF[7]);
+  if constexpr (!SMALL_IN) {
 #pragma unroll
-  for (int m = 0; m < 8; m++) c[m] = fred(c[m]);
+    for (int m = 0; m < 8; m++) c[m] = fred(c[m]);
+  }
   KY_WSYNC();
   f_put_stride(p, t, c);
   KY_WSYNC();
@@ -327,6 +334,24 @@ __device__ __forceinline__ void f_get_i16(const int16_t* p, int t, float (&c)[8]
   lds_get_contig(p, t, v);
 #pragma unroll
   for (int k = 0; k < 8; k++) c[k] = (float)v[k];
+}
+
+// 8 packed signed 16-bit values -> fp32 (one v_cvt_f32_i32 with a sign-extending sub-dword select each)
+__device__ __forceinline__ void s16x8_to_f(uint4 v, float (&f)[8]) {
+  f[0] = (float)(short)v.x; f[1] = (float)((int)v.x >> 16);
+  f[2] = (float)(short)v.y; f[3] = (float)((int)v.y >> 16);
+  f[4] = (float)(short)v.z; f[5] = (float)((int)v.z >> 16);
+  f[6] = (float)(short)v.w; f[7] = (float)((int)v.w >> 16);
+}
+// integer-valued floats, |c| < 2^15 -> 8 packed int16: adding 1.5 * 2^23 leaves the two's
+// complement value in the low mantissa bits (full-rate add instead of the half-rate
+// v_cvt_i32_f32), one v_perm_b32 joins two low halves
+__device__ __forceinline__ uint4 f_to_s16x8(const float (&c)[8]) {
+  uint32_t u[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) u[k] = __float_as_uint(c[k] + RND_MAGIC);
+  return make_uint4(__builtin_amdgcn_perm(u[1], u[0], 0x05040100u), __builtin_amdgcn_perm(u[3], u[2], 0x05040100u),
+                    __builtin_amdgcn_perm(u[5], u[4], 0x05040100u), __builtin_amdgcn_perm(u[7], u[6], 0x05040100u));
 }
 
 __device__ __forceinline__ void i2f8(const int (&c)[8], float (&f)[8]) {

@@ -146,3 +146,66 @@ def test_16bit_montgomery_forms_match_reference_reduce(oracle):
         want = (a - t * q) >> 16
         assert np.array_equal(got, want)
         assert np.all((got * 65536 - a) % q == 0) and np.all(np.abs(got) < q)
+
+
+def _fred32(x):
+    """fpoly.h fred on integer-valued int64 arrays, the FMA reproduced in float64."""
+    q, magic = 3329, 12582912.0
+    k = (x.astype(np.float64) * np.float64(np.float32(1.0) / np.float32(q)) + magic).astype(np.float32).astype(np.float64) - magic
+    return (x - (k * q).astype(np.int64))
+
+
+def test_cached_multiplicand_accumulation_stays_exact():
+    """fpoly.h FCache / f_corr / f_mac: base multiplication of canonical matrix
+    entries a in [0, q) against a cached centred multiplicand as unreduced FMA
+    chains that start at corr = -q * rne(1664 * S / q).  fp32 arithmetic on
+    integers is exact while every intermediate stays below 2^24, so the model
+    runs the kernel's operation order in int64 and checks (1) that bound for
+    worst-case sign patterns and random data, for one group of three
+    polynomials (Kyber768) and groups of two (Kyber512/1024), and (2) that the
+    reduced result is congruent to the reference's sum of basemul terms
+    (ref/ntt.c:139-146, ref/polyvec.c:194-198 without the Montgomery factors)."""
+    q, lim = 3329, 1 << 24
+    rng = np.random.default_rng(12)
+    n = 20000
+    for T in (2, 3):                       # polynomials per accumulation group
+        for mode in ("random", "worst+", "worst-", "max"):
+            b = rng.integers(-1665, 1666, (T, 2, n))      # b[j][0] = b[2p], b[j][1] = b[2p+1]
+            zb = rng.integers(-1665, 1666, (T, n))         # (+-zeta) * b[2p+1] mod q, any centred value
+            if mode == "max":
+                b = np.where(rng.integers(0, 2, b.shape) == 1, 1665, -1665)
+                zb = np.where(rng.integers(0, 2, zb.shape) == 1, 1665, -1665)
+            a = rng.integers(0, q, (T, 2, n))
+            if mode in ("worst+", "max"):  # a large exactly where the factor is positive: partial sums as positive as possible
+                a[:, 0] = np.where(b[:, 0] > 0, q - 1, 0)
+                a[:, 1] = np.where(zb > 0, q - 1, 0)
+            if mode == "worst-":
+                a[:, 0] = np.where(b[:, 0] > 0, 0, q - 1)
+                a[:, 1] = np.where(zb > 0, 0, q - 1)
+            for which in (0, 1):           # even output c[2p], odd output c[2p+1]
+                f0 = b[:, 0] if which == 0 else b[:, 1]   # factor of a[2p]
+                f1 = zb if which == 0 else b[:, 0]        # factor of a[2p+1]
+                S = (f0 + f1).sum(axis=0)
+                x = 1664 * S
+                assert np.abs(x).max() < lim
+                corr = -(x - _fred32(x))                  # -q * rne(x / q)
+                assert np.all(corr % q == 0) and np.abs(corr + x).max() <= 1665
+                acc = corr.copy()
+                peak = np.abs(acc).max()
+                for j in range(T):                        # f_mac: inner FMA first (a[2p+1] term), then the outer
+                    acc = acc + a[j, 1] * f1[j]
+                    peak = max(peak, np.abs(acc).max(), np.abs(a[j, 1] * f1[j]).max())
+                    acc = acc + a[j, 0] * f0[j]
+                    peak = max(peak, np.abs(acc).max())
+                assert peak < lim, (T, mode, which, peak)
+                want = sum(a[j, 0] * f0[j] + a[j, 1] * f1[j] for j in range(T))
+                r = _fred32(acc)
+                assert np.abs(r).max() <= 1665 and np.all((r - want) % q == 0)
+    # key bytes: any 12-bit value, centred by fred before f_mac; six products of centred values
+    a12 = np.arange(0, 4096, dtype=np.int64)
+    ac = _fred32(a12)
+    assert np.abs(ac).max() <= 1665 and np.all((ac - a12) % q == 0)
+    assert 6 * 1665 * 1665 < lim
+    # inverse transform without the final 1/128: outputs are sums of two reduced values,
+    # and the compression input bound of test_float_compress_formula_is_exact still holds
+    assert 2 * 1665 + 2 + 1665 <= 5000
