@@ -382,11 +382,11 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
 // ------------------------------------------------------------------ standalone polynomial kernels
 // (BASELINE.json config 2: batched NTT / basemul / inverse NTT on dense
 // arrays of int16[256] polynomials; 8 polynomials per 256-thread workgroup)
-// (The fp32 engine was tried for k_poly_ntt, whose Barrett-centred output depends
-// on residues only: 3.45 G NTT/s against 4.0 G/s for this int16 version, whose
-// LDS tiles are half the size.  invntt_tomont and basemul must stay integer in
-// any case: their Montgomery-path representatives in (-q, q) depend on the
-// integer arithmetic itself.)
+// The forward transform runs on the fp32 engine (below).  invntt_tomont and
+// basemul stay on the int16 engine: their outputs are the Montgomery path's
+// own representatives in (-q, q) -- montgomery_reduce returns the member of the
+// residue class nearest to p / 2^16, which depends on the exact integer p, not
+// on its residue -- so only the reference's integer sequence reproduces them.
 //
 // The transform kernels are grid-stride loops: a 32-lane group walks over
 // polynomials pi, pi + stride, ... and issues the 16-byte load of its next
@@ -404,43 +404,39 @@ __device__ __forceinline__ void st_poly16(int16_t* base, long pi, int t, const i
 // representative.  Inputs are any int16 the reference's int16 arithmetic can
 // take without overflow; a wavefront that sees a coefficient beyond the
 // engine's entry bound (4095) centres its inputs first.
-// The loop is unrolled by two over a ping-pong pair of load registers: with a
-// rotating queue (q[d] = q[d+1]) the register copies made the compiler wait for
-// every outstanding load and store at the top of each iteration (vmcnt(0)), so
-// nothing was ever in flight behind the transform.
+// Each pass of the loop takes U polynomials per group: all U loads are issued
+// first, then the polynomials are transformed and stored one after the other,
+// so the waits are counted (vmcnt(U-1), ...) and U-1 loads stay in flight behind
+// each transform.  (A load queue carried around the loop -- q[d] = q[d+1], or a
+// ping-pong pair -- made the compiler wait for everything in flight at the top
+// of each iteration, vmcnt(0): nothing overlapped.)
+template <int U>
 __global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ float ztab[128];
   const Grp w = grp();
   f_twiddles_to_lds(ztab);
   const long stride = (long)gridDim.x * 8;
-  long pi = (long)blockIdx.x * 8 + w.g;
-  auto transform = [&](const uint4& in, long at) {
-    float f[8];
-    s16x8_to_f(in, f);
-    const float big = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
-                            fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
-    if (__any(big > 4095.0f)) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) f[k] = fred(f[k]);
-    }
-    f_ntt_fwd(wk[w.g], ztab, w.t, f);
-    *reinterpret_cast<uint4*>(r + at * 256 + 8 * w.t) = f_to_s16x8(f);
-  };
-  // loads are unconditional (index clamped, surplus data unused): a load under a branch makes
-  // the number of operations in flight path-dependent and the compiler falls back to vmcnt(0)
   const long last = npoly - 1;
-  if (pi > last) return;
-  uint4 a = ld_poly16(r, pi, w.t), b;
-  while (true) {
-    b = ld_poly16(r, min(pi + stride, last), w.t);
-    transform(a, pi);
-    pi += stride;
-    if (pi > last) break;
-    a = ld_poly16(r, min(pi + stride, last), w.t);
-    transform(b, pi);
-    pi += stride;
-    if (pi > last) break;
+  for (long pi = (long)blockIdx.x * 8 + w.g; pi <= last; pi += U * stride) {
+    uint4 in[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) in[u] = ld_poly16(r, min(pi + u * stride, last), w.t);  // clamped: no load under a branch
+    __builtin_amdgcn_sched_barrier(0);  // every load is issued before the first one is waited for
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long at = pi + u * stride;
+      float f[8];
+      s16x8_to_f(in[u], f);
+      const float big = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+                              fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+      if (__any(big > 4095.0f)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) f[k] = fred(f[k]);
+      }
+      f_ntt_fwd(wk[w.g], ztab, w.t, f);
+      if (at <= last) *reinterpret_cast<uint4*>(r + at * 256 + 8 * w.t) = f_to_s16x8(f);
+    }
   }
 }
 

@@ -38,7 +38,9 @@ static inline unsigned stride_grid(size_t npoly) {
   const unsigned full = nblocks(npoly, 8), cap = 256 * 16;
   return full < cap ? full : cap;
 }
-void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_ntt<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
+// U = 1: tools/microbench/ntt_ablate.hip measured U = 1, 2, 4 within 3 % of each other and of the
+// bare load-convert-store loop (the kernel runs at its access pattern's copy rate); U = 1 keeps 8 waves per SIMD
+void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_ntt<1><<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
 void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_invntt<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
 void launch_poly_basemul(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
   k_poly_basemul<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, a, b);
