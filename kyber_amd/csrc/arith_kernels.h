@@ -335,48 +335,67 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
 
 // ------------------------------------------------------------------ decryption arithmetic
 // ref/indcpa.c:318-328: m' = tomsg(v - invntt(s^ . NTT(decompress(u))))
+// One 32-lane group per instance, as in k_enc_arith.  The ciphertext is staged
+// in LDS with 16-byte loads (its 10/11-bit fields start at byte offsets that
+// would otherwise cost ten single-byte global loads per work-item and
+// polynomial); s^ arrives as 12 key bytes per work-item and polynomial.
 template <class P>
 __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
                                                    size_t sk_stride, uint8_t* __restrict__ small) {
-  constexpr int K = P::K;
-  __shared__ __attribute__((aligned(16))) int16_t uh[G_INST][K][256];
+  constexpr int K = P::K, CT16 = P::CTB / 16;
+  using G = FcGroups<K>;
+  __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
-  f_twiddles_to_lds(ztab);
-
-  for (int q = w.g; q < G_INST * K; q += 8) {
-    const int li = q / K, j = q % K;
-    const int gi = min(inst0 + li, n - 1);
-    int c[8];
-    float f[8];
-    decompress_contig<P::DU>(ct + (size_t)gi * P::CTB + P::UB * j, w.t, c);
-    i2f8(c, f);
-    f_ntt_fwd(wk[w.g], ztab, w.t, f);
-    f_put_i16(uh[li][j], w.t, f);
-  }
-  __syncthreads();
+  const int li = w.g;
+  const int gi = min(inst0 + li, n - 1);
+  const uint8_t* sk_i = sk + (size_t)gi * sk_stride;
   {
-    const int li = w.g;  // G_INST == number of groups: one result polynomial each
-    const int gi = min(inst0 + li, n - 1);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a[8], b[8];
+    const uint4* src = reinterpret_cast<const uint4*>(ct + (size_t)gi * P::CTB);
+    uint4* dst = reinterpret_cast<uint4*>(ctb[li]);
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      ld_bytes12f(sk + (size_t)gi * sk_stride + 384 * j, w.t, a);
-      f_get_i16(uh[li][j], w.t, b);
-      f_basemul_acc(acc, a, b, ztab, w.t);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
-    f_ntt_inv(wk[w.g], ztab, w.t, acc);
-    int v[8];
-    decompress_contig<P::DV>(ct + (size_t)gi * P::CTB + P::UB * K, w.t, v);
-    unsigned byte = 0;  // poly_tomsg: bit k = round(2 x / q) & 1       ref/poly.c:180-194
-#pragma unroll
-    for (int k = 0; k < 8; k++) byte |= fcompress<1>((float)v[k] - acc[k]) << k;  // |.| <= 3328 + 1668
-    if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)byte;
+    for (int o = 0; o < (CT16 + 31) / 32; o++)
+      if (o * 32 + w.t < CT16) dst[o * 32 + w.t] = src[o * 32 + w.t];
   }
+  uint32_t sb[K][3];
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(sk_i + 384 * j) + 3 * w.t;
+    sb[j][0] = p[0]; sb[j][1] = p[1]; sb[j][2] = p[2];
+  }
+  f_twiddles_to_lds(ztab);  // ends with a workgroup barrier: the staged ciphertext is visible too
+
+  float acc[8];
+#pragma unroll
+  for (int g = 0; g < G::N; g++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = (g == 0) ? 0.0f : fred(acc[k]);
+#pragma unroll
+    for (int j = G::begin(g); j < G::end(g); j++) {
+      int c[8];
+      float u[8], s[8];
+      decompress_contig<P::DU>(ctb[li] + P::UB * j, w.t, c);
+      i2f8(c, u);
+      f_ntt_fwd(wk[w.g], ztab, w.t, u);  // centred, |u| <= 1665
+      frombytes12(sb[j][0], sb[j][1], sb[j][2], c);
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = fred((float)c[k]);  // key bytes carry any 12-bit value: centre them
+      FCache sc;
+      f_cache_make(sc, s, ztab, w.t);
+      f_mac(acc, u, sc);  // six products of centred values per coefficient at most (fpoly.h)
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
+  f_ntt_inv(wk[w.g], ztab, w.t, acc);
+  int v[8];
+  decompress_contig<P::DV>(ctb[li] + P::UB * K, w.t, v);
+  unsigned byte = 0;  // poly_tomsg: bit k = round(2 x / q) & 1       ref/poly.c:180-194
+#pragma unroll
+  for (int k = 0; k < 8; k++) byte |= fcompress<1>((float)v[k] - acc[k]) << k;  // |.| <= 3328 + 1668
+  if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)byte;
 }
 
 // ------------------------------------------------------------------ standalone polynomial kernels

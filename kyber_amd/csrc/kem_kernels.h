@@ -238,19 +238,22 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 }
 __device__ __forceinline__ void lds_st16(uint32_t addr, uint32_t v) { *(lds_u16*)(uintptr_t)addr = (uint16_t)v; }
 
-template <int G, int N>
-__device__ __forceinline__ void parse_group(const uint32_t (&H)[N], uint32_t& waddr) {
+// FIXED (tools/microbench only): store at a cursor-independent address, to price the bank
+// conflicts that diverging cursors cause
+template <int G, int N, bool FIXED = false>
+__device__ __forceinline__ void parse_group(const uint32_t (&H)[N], uint32_t& waddr, uint32_t fixed = 0) {
   uint32_t d1 = field12<24 * G, N>(H), d2 = field12<24 * G + 12, N>(H);
-  lds_st16(waddr, d1);
+  if (FIXED && fixed == 0) asm volatile("" ::"v"(d1), "v"(d2));  // no staging stores at all
+  else lds_st16(FIXED ? fixed + 4 * (G % 28) : waddr, d1);
   waddr += accept_step(d1);
-  lds_st16(waddr, d2);
+  if (!(FIXED && fixed == 0)) lds_st16(FIXED ? fixed + 4 * (G % 28) + 2 : waddr, d2);
   waddr += accept_step(d2);
 }
-template <int G0, int G1, int N>
-__device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& waddr) {
+template <int G0, int G1, int N, bool FIXED = false>
+__device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& waddr, uint32_t fixed = 0) {
   if constexpr (G0 < G1) {
-    parse_group<G0, N>(H, waddr);
-    parse_range<G0 + 1, G1, N>(H, waddr);
+    parse_group<G0, N, FIXED>(H, waddr, fixed);
+    parse_range<G0 + 1, G1, N, FIXED>(H, waddr, fixed);
   }
 }
 
@@ -311,7 +314,7 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
   }
 }
 
-template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either)
+template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either, 3: no drain, conflict-free staging stores, 4: no drain, no staging stores)
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                        int transposed, int16_t* __restrict__ mat,
                                                        uint32_t* __restrict__ tailq, uint32_t tail_cap) {
@@ -349,7 +352,9 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
       // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
       const uint32_t w0 = row_addr + 2u * (ctr & 1);
       uint32_t waddr = w0;
-      if constexpr (ABLATE < 2) {
+      if constexpr (ABLATE == 3 || ABLATE == 4) {
+        parse_range<G0, G0 + MAT_GROUPS, 42, true>(H, waddr, ABLATE == 3 ? row_addr : 0u);
+      } else if constexpr (ABLATE < 2) {
         parse_range<G0, G0 + MAT_GROUPS, 42>(H, waddr);
       } else {
 #pragma unroll

@@ -296,10 +296,16 @@ template <int D>
 __device__ __forceinline__ void decompress_contig(const uint8_t* in, int t, int (&c)[8]) {
   const uint8_t* p = in + D * t;
   unsigned long long lo = 0, hi = 0;
+  // widest loads the alignment of in + D*t allows (`in` is 4-byte aligned)
+  constexpr int W = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
 #pragma unroll
-  for (int b = 0; b < D; b++) {
-    if (b < 8) lo |= (unsigned long long)p[b] << (8 * b);
-    else hi |= (unsigned long long)p[b] << (8 * (b - 8));
+  for (int b = 0; b < D; b += W) {
+    unsigned long long x;
+    if constexpr (W == 4) x = *reinterpret_cast<const uint32_t*>(p + b);
+    else if constexpr (W == 2) x = *reinterpret_cast<const uint16_t*>(p + b);
+    else x = p[b];
+    if (b < 8) lo |= x << (8 * b);
+    else hi |= x << (8 * (b - 8));
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {

@@ -1,6 +1,10 @@
 // matrix_ablate.hip -- where does k_sample_matrix spend its time?  Runs the
-// product kernel (ABLATE=0) and two ablations (1: no drain, 2: no parse, no
-// drain) interleaved in one process on the same seeds.
+// product kernel (ABLATE=0) and ablations (1: no drain; 2: no parse, no drain;
+// 3: no drain, staging stores at cursor-independent, bank-conflict-free addresses;
+// 4: no drain, parse arithmetic without any staging store) interleaved in one
+// process on the same seeds.  No tail queue is passed here, so every variant
+// except 2 also runs the 4th SHAKE block for the 41 % of wavefronts that hold a
+// short entry (the product hands those entries to k_sample_matrix_tail).
 #include "../../kyber_amd/csrc/kem_kernels.h"
 #include <cstdio>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -22,8 +26,8 @@ int main() {
   { std::vector<uint32_t> h(n * 8); for (int i = 0; i < n * 8; i++) h[i] = i * 2654435761u; CK(hipMemcpy(seeds, h.data(), n * 32, hipMemcpyHostToDevice)); }
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int r = 0; r < 4; r++) {
-    float t0 = run<0>(n, seeds, mat, a, b), t1 = run<1>(n, seeds, mat, a, b), t2 = run<2>(n, seeds, mat, a, b);
-    printf("round %d: full %.3f ms | no drain %.3f ms | perm only %.3f ms   (n=%d x 9 entries)\n", r, t0, t1, t2, n);
+    float t0 = run<0>(n, seeds, mat, a, b), t1 = run<1>(n, seeds, mat, a, b), t2 = run<2>(n, seeds, mat, a, b), t3 = run<3>(n, seeds, mat, a, b), t4 = run<4>(n, seeds, mat, a, b);
+    printf("round %d: full %.3f ms | no drain %.3f ms | no drain, conflict-free staging stores %.3f ms | parse without stores %.3f ms | perm only %.3f ms   (n=%d x 9 entries)\n", r, t0, t1, t3, t4, t2, n);
   }
   CK(hipDeviceSynchronize());
   return 0;
