@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/round_profiles.sh <rNN> -- everything the round's profiles/ entries come from, in one GPU call:
+# the default bench line, the side workloads, rocprofv3 kernel-trace stats of the same commands and the
+# counter passes (tools/pmc_all.sh).  Outputs land in gpurun_out/<rNN>_*; tools/round_profiles_collect.py
+# copies the summaries into profiles/.
+set -e
+R=$1
+export TMPDIR=/tmp
+timeout -k 10 300 python3 bench.py > gpurun_out/${R}_bench_kyber768.json 2> gpurun_out/${R}_bench_kyber768.err
+for w in kyber512 kyber1024 kyber768-90s; do
+  timeout -k 10 200 python3 bench.py --workload $w --steps 5 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_bench_$w.json 2>/dev/null
+done
+timeout -k 10 200 python3 bench.py --shared-key --steps 5 --no-cpu-baseline > gpurun_out/${R}_bench_kyber768_shared_key.json 2>/dev/null
+timeout -k 10 200 python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun_out/${R}_bench_ntt.json 2>/dev/null
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_kem --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_prof_kem.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_ntt --output-format csv -- python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun_out/${R}_prof_ntt.log 2>&1
+tools/pmc_all.sh $R

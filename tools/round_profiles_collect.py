@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""tools/round_profiles_collect.py <run-prefix> <profile-prefix> -- copy what tools/round_profiles.sh left under
+gpurun_out/ (scratch) into profiles/ (tracked): bench lines, rocprofv3 kernel stats, counter summaries.
+   python3 tools/round_profiles_collect.py r02b r02"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+run, out = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+for f in glob.glob(os.path.join(G, run + "_bench_*.json")):
+    shutil.copy(f, os.path.join(P, os.path.basename(f).replace(run + "_", out + "_")))
+for tag in ("kem", "ntt"):
+    for f in glob.glob(os.path.join(G, "%s_prof_%s" % (run, tag), "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (out, tag)))
+summ = os.path.join(ROOT, "tools", "pmc_summarize.py")
+for tag, name in (("", "kem"), ("_ntt", "ntt")):
+    sq = [os.path.join(G, "pmc_%s%s_sq%d" % (run, tag, i)) for i in (1, 2)]
+    with open(os.path.join(P, "%s_pmc_sq_%s.txt" % (out, name)), "w") as fh:
+        subprocess.run([sys.executable, summ] + sq, stdout=fh, check=True)
+    tr = [os.path.join(G, "pmc_%s%s_%s" % (run, tag, c)) for c in ("fetch", "write")]
+    with open(os.path.join(P, "%s_pmc_traffic%s.json" % (out, "" if name == "kem" else "_ntt")), "w") as fh:
+        subprocess.run([sys.executable, summ, "--traffic-json"] + tr, stdout=fh, check=True)
+print("\n".join(sorted(os.listdir(P))))
