@@ -1,0 +1,44 @@
+// fusion_bound.hip -- what would a fused "sample the matrix into LDS, consume it in
+// the same workgroup" kernel run at?  
+// A is 512 bytes per entry and a sponge-layout wavefront holds 64 entries, so a
+// workgroup of 256 sponges needs 28 instances x 9 entries x 512 B = 129 KB of LDS for
+// the tile alone: ONE workgroup per CU, one wavefront per SIMD.  This program runs
+// the two product kernels at exactly that residency (dynamic LDS padding, nothing
+// else changed) next to their normal residency, which prices the fusion's
+// occupancy cost without writing the fused kernel; the traffic it would save is
+// priced by matrix_ablate (drain) and by the shared-matrix run of bench.py.
+#include "../../kyber_amd/csrc/kem_kernels.h"
+#include "../../kyber_amd/csrc/arith_kernels.h"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using P = ky::Par<3>;
+
+int main() {
+  const int n = 1 << 17;
+  uint8_t *seeds, *pk, *small, *prf, *ct; int16_t* mat;
+  CK(hipMalloc(&seeds, n * 32)); CK(hipMalloc(&mat, (size_t)n * 9 * 512)); CK(hipMalloc(&pk, (size_t)n * P::PKB));
+  CK(hipMalloc(&small, (size_t)n * 128)); CK(hipMalloc(&prf, (size_t)n * 7 * 128)); CK(hipMalloc(&ct, (size_t)n * P::CTB));
+  { std::vector<uint32_t> h(n * 8); for (int i = 0; i < n * 8; i++) h[i] = i * 2654435761u; CK(hipMemcpy(seeds, h.data(), n * 32, hipMemcpyHostToDevice)); }
+  CK(hipMemset(pk, 0x11, (size_t)n * P::PKB)); CK(hipMemset(small, 0x22, (size_t)n * 128)); CK(hipMemset(prf, 0x33, (size_t)n * 7 * 128));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  auto k_s = ky::k_sample_matrix<P, 0>;
+  auto k_e = ky::k_enc_arith<P, false>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_e), hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024));
+  const int jobs = n * 9;
+  for (int r = 0; r < 3; r++) {
+    float t[4];
+    for (int v = 0; v < 4; v++) {
+      const size_t pad = (v & 1) ? ((v < 2) ? 120 * 1024 : 130 * 1024) : 0;  // forces one workgroup per CU
+      CK(hipEventRecord(a));
+      if (v < 2) k_s<<<(jobs + 255) / 256, 256, pad>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
+      else k_e<<<(n + 7) / 8, 256, pad>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&t[v], a, b));
+    }
+    printf("round %d (n = %d): k_sample_matrix %.3f ms, at one workgroup per CU %.3f ms (x%.2f) | k_enc_arith %.3f ms, at one workgroup per CU %.3f ms (x%.2f)\n",
+           r, n, t[0], t[1], t[1] / t[0], t[2], t[3], t[3] / t[2]);
+  }
+  return 0;
+}
