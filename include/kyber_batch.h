@@ -63,6 +63,18 @@ int kyber_batch_keypair(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk,
 int kyber_batch_enc(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins /* n*32 or NULL */);
 int kyber_batch_dec(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);
 
+/* ---- one node, several GPUs ----
+ * The same three calls with the batch cut into `ndev` contiguous shards, shard g
+ * on HIP device devices[g] (devices == NULL: devices 0 .. ndev-1), each driven by
+ * a host thread of its own through the host-memory call above.  Instances are
+ * independent (the reference's functions share no state, ref/kem.c:23-127), so no
+ * device exchanges anything with another; results are byte for byte those of the
+ * single-device call.  A device may be named more than once (its shards then
+ * queue behind each other).  coins == NULL draws from randombytes() per shard. */
+int kyber_batch_keypair_mgpu(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins, int ndev, const int *devices);
+int kyber_batch_enc_mgpu(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, int ndev, const int *devices);
+int kyber_batch_dec_mgpu(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, int ndev, const int *devices);
+
 /* ---- device-memory batch calls ----
  * Every pointer is device memory on the current HIP device (coins must not be
  * NULL); work is enqueued on `stream` (a hipStream_t passed as void*, NULL =

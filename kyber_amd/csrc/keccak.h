@@ -123,10 +123,21 @@ __device__ __forceinline__ void keccak_absorb_words(u64p (&A)[25], const uint8_t
   constexpr int RW = RATE / 8, NFULL = LEN / RATE, TAILW = (LEN % RATE) / 8;
   keccak_zero(A);
   if constexpr (NFULL > 0) {
+    // The words of block b+1 are requested before block b is permuted.  Every wavefront
+    // of these kernels does the same work at the same pace, so without this they all sit
+    // in their load phase together and the SIMD idles for a memory round trip per block.
+    // The last pass re-reads the last full block (index clamped: no load under a branch,
+    // so the wait in front of the xor stays counted); TAILW words are fetched afterwards.
+    u64p nx[RW];
+#pragma unroll
+    for (int w = 0; w < RW; w++) nx[w] = ld64(in + 8 * w);
 #pragma unroll 1
     for (int b = 0; b < NFULL; b++) {
 #pragma unroll
-      for (int w = 0; w < RW; w++) A[w] ^= ld64(in + 8 * (b * RW + w));
+      for (int w = 0; w < RW; w++) A[w] ^= nx[w];
+      const uint8_t* nb = in + 8 * RW * (b + 1 < NFULL ? b + 1 : b);
+#pragma unroll
+      for (int w = 0; w < RW; w++) nx[w] = ld64(nb + 8 * w);
       keccak_f1600(A);
     }
   }

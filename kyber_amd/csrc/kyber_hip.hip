@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <mutex>
+#include <thread>
+#include <algorithm>
 #include <vector>
 #include <map>
 #include <string>
@@ -1004,6 +1006,74 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, c
   if (!npoly) return 0;
   RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), launch_poly_mul_fused(static_cast<hipStream_t>(stream), npoly, r, a, b));
   return 0;
+}
+
+// ---- one node, several GPUs: contiguous shards, one host thread per device ----
+// Instances share nothing (ref/kem.c:23-127 keep no state), so shard g of G is instances
+// [g*n/G, (g+1)*n/G) of every array, run through the ordinary host-pointer entry point on
+// device devices[g] by a thread of its own; no device talks to another.
+extern "C++" {
+namespace {
+template <class F>
+int run_sharded(size_t n, int ndev, const int* devices, F&& shard_call) {
+  if (ndev < 1 || ndev > MAX_DEV) return KYBER_HIP_EINVAL;
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  for (int g = 0; g < ndev; g++) {
+    const int d = devices ? devices[g] : g;
+    if (d < 0 || d >= count) {
+      snprintf(g_err, sizeof g_err, "device %d not present (%d visible)", d, count);
+      return KYBER_HIP_EINVAL;
+    }
+  }
+  std::vector<int> rc(ndev, 0);
+  std::vector<std::string> err(ndev);
+  std::vector<std::thread> th;
+  for (int g = 0; g < ndev; g++) {
+    const size_t lo = n / ndev * g + std::min<size_t>(g, n % ndev);
+    const size_t cnt = n / ndev + ((size_t)g < n % ndev ? 1 : 0);
+    const int d = devices ? devices[g] : g;
+    th.emplace_back([&, g, lo, cnt, d] {
+      if (cnt == 0) return;
+      hipError_t e = hipSetDevice(d);  // the current device is per host thread
+      rc[g] = e == hipSuccess ? shard_call(lo, cnt) : hip_fail(e, "hipSetDevice");
+      if (rc[g]) err[g] = g_err;  // g_err is thread-local: hand the text to the caller's thread
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int g = 0; g < ndev; g++)
+    if (rc[g]) {
+      snprintf(g_err, sizeof g_err, "shard %d: %s", g, err[g].c_str());
+      return rc[g];
+    }
+  return 0;
+}
+}  // namespace
+}  // extern "C++"
+
+int kyber_batch_keypair_mgpu(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, int ndev,
+                             const int* devices) {
+  if (!pk || !sk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  const size_t pkb = kyber_hip_pk_bytes(k), skb = kyber_hip_sk_bytes(k);
+  return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
+    return kyber_batch_keypair(k, nineties, cnt, pk + lo * pkb, sk + lo * skb, coins ? coins + lo * 64 : nullptr);
+  });
+}
+int kyber_batch_enc_mgpu(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, int ndev,
+                         const int* devices) {
+  if (!ct || !ss || !pk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  const size_t pkb = kyber_hip_pk_bytes(k), ctb = kyber_hip_ct_bytes(k);
+  return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
+    return kyber_batch_enc(k, nineties, cnt, ct + lo * ctb, ss + lo * 32, pk + lo * pkb, coins ? coins + lo * 32 : nullptr);
+  });
+}
+int kyber_batch_dec_mgpu(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, int ndev,
+                         const int* devices) {
+  if (!ss || !ct || !sk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  const size_t skb = kyber_hip_sk_bytes(k), ctb = kyber_hip_ct_bytes(k);
+  return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
+    return kyber_batch_dec(k, nineties, cnt, ss + lo * 32, ct + lo * ctb, sk + lo * skb);
+  });
 }
 
 void* kyber_hip_host_alloc(size_t bytes) {

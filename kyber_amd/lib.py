@@ -67,6 +67,9 @@ def library():
         "kyber_batch_keypair": [ci, ci, sz, u8p, u8p, u8p],
         "kyber_batch_enc": [ci, ci, sz, u8p, u8p, u8p, u8p],
         "kyber_batch_dec": [ci, ci, sz, u8p, u8p, u8p],
+        "kyber_batch_keypair_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
+        "kyber_batch_enc_mgpu": [ci, ci, sz, u8p, u8p, u8p, u8p, ci, vp],
+        "kyber_batch_dec_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
         "kyber_batch_keypair_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_enc_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
@@ -186,6 +189,41 @@ class KyberHip:
         sk = _np_u8(np.asarray(sk).reshape(-1, self.sk_bytes), (n, self.sk_bytes), "sk")
         ss = np.empty((n, 32), np.uint8)
         _check(self.lib.kyber_batch_dec(self.k, self.nineties, n, _ptr(ss), _ptr(ct), _ptr(sk)), "kyber_batch_dec")
+        return ss
+
+    # ---- several GPUs of one node (host arrays; contiguous shards, one host thread per device) ----
+    @staticmethod
+    def _devs(devices):
+        devs = list(devices)
+        return len(devs), (ctypes.c_int * len(devs))(*devs)
+
+    def keypair_mgpu(self, coins, devices):
+        coins = np.ascontiguousarray(coins, dtype=np.uint8).reshape(-1, 64)
+        n = coins.shape[0]
+        pk, sk = np.empty((n, self.pk_bytes), np.uint8), np.empty((n, self.sk_bytes), np.uint8)
+        nd, arr = self._devs(devices)
+        _check(self.lib.kyber_batch_keypair_mgpu(self.k, self.nineties, n, _ptr(pk), _ptr(sk), _ptr(coins), nd, arr),
+               "kyber_batch_keypair_mgpu")
+        return pk, sk
+
+    def enc_mgpu(self, pk, coins, devices):
+        pk = np.ascontiguousarray(pk, dtype=np.uint8).reshape(-1, self.pk_bytes)
+        n = pk.shape[0]
+        coins = _np_u8(np.asarray(coins).reshape(-1, 32), (n, 32), "coins")
+        ct, ss = np.empty((n, self.ct_bytes), np.uint8), np.empty((n, 32), np.uint8)
+        nd, arr = self._devs(devices)
+        _check(self.lib.kyber_batch_enc_mgpu(self.k, self.nineties, n, _ptr(ct), _ptr(ss), _ptr(pk), _ptr(coins), nd, arr),
+               "kyber_batch_enc_mgpu")
+        return ct, ss
+
+    def dec_mgpu(self, ct, sk, devices):
+        ct = np.ascontiguousarray(ct, dtype=np.uint8).reshape(-1, self.ct_bytes)
+        n = ct.shape[0]
+        sk = _np_u8(np.asarray(sk).reshape(-1, self.sk_bytes), (n, self.sk_bytes), "sk")
+        ss = np.empty((n, 32), np.uint8)
+        nd, arr = self._devs(devices)
+        _check(self.lib.kyber_batch_dec_mgpu(self.k, self.nineties, n, _ptr(ss), _ptr(ct), _ptr(sk), nd, arr),
+               "kyber_batch_dec_mgpu")
         return ss
 
     # ---- one key, many operations (host arrays) ----

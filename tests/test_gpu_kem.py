@@ -76,3 +76,28 @@ def test_matrix_tail_queue_capacity(oracle, cap):
     oct_, oss = oracle.enc(k, opk, ec)
     assert np.array_equal(pk, opk) and np.array_equal(sk, osk)
     assert np.array_equal(ct, oct_) and np.array_equal(ss, oss) and np.array_equal(ss2, oss)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_device_entry_points_shard_contiguously(oracle, devices):
+    """kyber_batch_*_mgpu: contiguous shards, one host thread per listed device.
+    On a one-GPU box every shard names device 0 (they queue behind each other);
+    the bytes must be those of the single-device call and of the oracle, also
+    when n does not divide by the shard count."""
+    k, n = 3, 1001
+    kem = kyber_amd.KyberHip(k)
+    kc, ec = _coins(n, 64, 501), _coins(n, 32, 502)
+    pk, sk = kem.keypair_mgpu(kc, devices)
+    ct, ss = kem.enc_mgpu(pk, ec, devices)
+    ss2 = kem.dec_mgpu(ct, sk, devices)
+    opk, osk = oracle.keypair(k, kc)
+    oct_, oss = oracle.enc(k, opk, ec)
+    assert np.array_equal(pk, opk) and np.array_equal(sk, osk)
+    assert np.array_equal(ct, oct_) and np.array_equal(ss, oss) and np.array_equal(ss2, oss)
+
+
+def test_multi_device_rejects_absent_device():
+    from kyber_amd import lib as kl
+    kem = kyber_amd.KyberHip(3)
+    with pytest.raises(kl.KyberHipError, match="not present"):
+        kem.keypair_mgpu(_coins(4, 64, 1), [0, 63])

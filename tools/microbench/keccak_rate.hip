@@ -51,6 +51,42 @@ int main() {
     if (run<4>(d, n, 64)) return 1;
     CK(hipFree(d));
   }
+  // sustained rate: the same launch back to back for about two seconds (the chip lowers its clock
+  // under sustained load; a single 7 ms launch from idle runs on boost)
+  {
+    const int n = 256 * 256 * 16;
+    uint2* d; CK(hipMalloc(&d, (size_t)n * 25 * 8)); CK(hipMemset(d, 0x5a, (size_t)n * 25 * 8));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int phase = 0; phase < 6; phase++) {
+      CK(hipEventRecord(a));
+      for (int r = 0; r < 50; r++) k_perm<4><<<n / 256, 256>>>(d, n, 64);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      printf("sustained, launches %3d-%3d: %.3f G perm/s\n", phase * 50, phase * 50 + 49, (double)n * 64 * 50 / (ms * 1e-3) * 1e-9);
+    }
+    CK(hipFree(d));
+  }
+  // rate against the number of resident wavefronts per SIMD (dynamic LDS padding limits residency;
+  // the kernel's registers allow 6): how much do the sponge kernels lose to their 4-6 waves per SIMD?
+  {
+    const int n = 256 * 256 * 16;
+    uint2* d; CK(hipMalloc(&d, (size_t)n * 25 * 8)); CK(hipMemset(d, 0x5a, (size_t)n * 25 * 8));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_perm<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int w = 1; w <= 8; w++) {
+      const size_t pad = w == 8 ? 0 : (size_t)(160 * 1024 / w) & ~(size_t)255;
+      float best = 1e30f;
+      for (int r = 0; r < 4; r++) {
+        CK(hipEventRecord(a));
+        k_perm<4><<<n / 256, 256, pad>>>(d, n, 64);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+      }
+      printf("at most %d workgroups (= waves per SIMD) per CU by LDS: %.3f G perm/s\n", w, (double)n * 64 / (best * 1e-3) * 1e-9);
+    }
+    CK(hipFree(d));
+  }
   // known-answer: permutation of the all-zero state, first lane = 0xF1258F7940E1DDE7
   uint2* d; CK(hipMalloc(&d, 256 * 25 * 8)); CK(hipMemset(d, 0, 256 * 25 * 8));
   k_perm<2><<<1, 256>>>(d, 256, 1);
