@@ -9,10 +9,11 @@ goes to the HIP library and fails loudly if it is missing or no GPU is present.
 from .lib import (  # noqa: F401
     KyberHip,
     KyberHipError,
+    MlKemHip,
     PARAMETER_SETS,
     library,
     library_path,
     sizes,
 )
 
-__all__ = ["KyberHip", "KyberHipError", "PARAMETER_SETS", "library", "library_path", "sizes"]
+__all__ = ["KyberHip", "KyberHipError", "MlKemHip", "PARAMETER_SETS", "library", "library_path", "sizes"]

@@ -169,6 +169,118 @@ __global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__
   st32B(ss + (size_t)i * 32, A[0], A[1], A[2], A[3]);
 }
 
+// ------------------------------------------------------------------ ML-KEM (FIPS 203) FO glue
+// Not in the reference: the same K-PKE underneath -- matrix, noise,
+// transforms and codecs are bit for bit those of round-3 Kyber -- with the final standard's
+// key derivation around it.  FIPS 203 algorithms 13 (K-PKE.KeyGen, G(d || k)), 17
+// (Encaps_internal: (K, r) = G(m || H(ek)), no hashing of m, no KDF) and 18
+// (Decaps_internal: implicit rejection key J(z || c) = SHAKE256(z || c, 32)).
+
+// keypair, before: (rho, sigma) = G(d || k)
+__global__ void __launch_bounds__(256) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p d[4], A[25];
+  ld32B(coins + (size_t)i * 64, d);
+  keccak_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = d[w];
+  A[4].lo = (uint32_t)k | 0x0600u;  // byte 32 = k, then the SHA3 domain byte
+  A[8].hi = 0x80000000u;
+  keccak_f1600(A);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32B(s, A[0], A[1], A[2], A[3]);
+  st32B(s + 32, A[4], A[5], A[6], A[7]);
+}
+
+// encaps: (K, r) = G(m || H(ek)); the shared secret is K itself
+template <class P>
+__global__ void __launch_bounds__(256) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                    uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25], m[4], h[4];
+  ld32B(coins + (size_t)i * 32, m);
+  keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
+#pragma unroll
+  for (int w = 0; w < 4; w++) h[w] = A[w];
+  sha3_512_64(A, m, h);
+  uint8_t* s = small + (size_t)i * SMALL;
+  st32B(s, m[0], m[1], m[2], m[3]);
+  st32B(ss + (size_t)i * 32, A[0], A[1], A[2], A[3]);
+  st32B(s + 64, A[4], A[5], A[6], A[7]);
+}
+
+// decaps, after: ss = (c == c') ? K' : J(z || c), selected without a branch
+template <class P>
+__global__ void __launch_bounds__(256) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+                                                     const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  constexpr int RW = 17, TOTW = 4 + P::CTB / 8, NFULL = TOTW / RW, TAILW = TOTW % RW;
+  const uint8_t* c = ct + (size_t)i * P::CTB;
+  u64p A[25], z[4], kb[4];
+  ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 64, z);
+  keccak_zero(A);
+  // block 0: z, then the first 13 words of c; every later block is 17 consecutive words of c
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = z[w];
+#pragma unroll
+  for (int w = 4; w < RW; w++) A[w] ^= ld64(c + 8 * (w - 4));
+  keccak_f1600(A);
+#pragma unroll 1
+  for (int b = 1; b < NFULL; b++) {
+#pragma unroll
+    for (int w = 0; w < RW; w++) A[w] ^= ld64(c + 8 * (b * RW + w - 4));
+    keccak_f1600(A);
+  }
+#pragma unroll
+  for (int w = 0; w < TAILW; w++) A[w] ^= ld64(c + 8 * (NFULL * RW + w - 4));
+  A[TAILW].lo ^= 0x1Fu;
+  A[RW - 1].hi ^= 0x80000000u;
+  keccak_f1600(A);
+  const uint8_t* s = small + (size_t)i * SMALL;
+  ld32B(s + 32, kb);
+  const uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
+  u64p o[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    o[w].lo = kb[w].lo ^ (mask & (kb[w].lo ^ A[w].lo));
+    o[w].hi = kb[w].hi ^ (mask & (kb[w].hi ^ A[w].hi));
+  }
+  st32B(ss + (size_t)i * 32, o[0], o[1], o[2], o[3]);
+}
+
+// Input checks of FIPS 203 7.2 / 7.3 as per-instance flags (0 = passes):
+//   ek: every 12-bit coefficient of the encoded t^ is below q ("modulus check")
+//   dk: the same for the embedded ek, and H(ek) equals the stored hash ("hash check")
+template <class P, bool DK>
+__global__ void __launch_bounds__(256) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* ek = key + (size_t)i * (DK ? P::SKB : P::PKB) + (DK ? P::PVB : 0);
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (int w = 0; w < P::PVB / 12; w++) {  // three dwords = eight coefficients
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(ek) + 3 * w;
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t c[8] = {w0 & 0xFFF, (w0 >> 12) & 0xFFF, (w0 >> 24 | w1 << 8) & 0xFFF, (w1 >> 4) & 0xFFF,
+                           (w1 >> 16) & 0xFFF, (w1 >> 28 | w2 << 4) & 0xFFF, (w2 >> 8) & 0xFFF, w2 >> 20};
+#pragma unroll
+    for (int k = 0; k < 8; k++) bad |= (uint32_t)(Q - 1 - (int)c[k]) >> 31;
+  }
+  if constexpr (DK) {
+    u64p A[25], h[4];
+    keccak_absorb_words<136, 0x06, P::PKB>(A, ek);
+    ld32B(ek + P::PKB, h);
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) d |= (A[w].lo ^ h[w].lo) | (A[w].hi ^ h[w].hi);
+    bad |= ((d | (0u - d)) >> 31) << 1;
+  }
+  flags[i] = bad;
+}
+
 // ------------------------------------------------------------------ SHAKE256 PRF
 // One work-item per (nonce, instance); jobs are nonce-major so a wavefront is
 // uniform in the output length.  Writes the raw PRF bytes; the centred

@@ -21,6 +21,7 @@
 
 #include "../../include/kyber_batch.h"
 #include "../../include/kyber_api.h"
+#include "../../include/mlkem_batch.h"
 #include "kem_kernels_90s.h"
 #include "arith_launch.h"
 
@@ -354,6 +355,81 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
   return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st);
+}
+
+// ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
+template <class P>
+int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
+  WsUse use(st);
+  if (use.rc) return use.rc;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* c = coins + o * 64;
+    uint8_t *p = ek + o * P::PKB, *s = dk + o * P::SKB;
+    RUN("k_ml_kp_pre", st, k_ml_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, P::K, c, L.small));
+    if (int rc = expand_matrix<P, false>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
+    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));  // dk tail = H(ek) || z, as in round 3
+  }
+  return 0;
+}
+
+template <class P>
+int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
+  WsUse use(st);
+  if (use.rc) return use.rc;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* p = ek + o * P::PKB;
+    uint8_t* c = ct + o * P::CTB;
+    RUN("k_ml_enc_pre", st, k_ml_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, L.small, ss + o * 32));
+    if (int rc = expand_matrix<P, false>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    RUN("k_enc_arith", st, launch_enc_arith<P, false>(st, m, p, P::PKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, c));
+  }
+  return 0;
+}
+
+template <class P>
+int ml_dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
+  WsUse use(st);
+  if (use.rc) return use.rc;
+  const size_t gc = g_chunk.load();
+  const size_t chunk = n < gc ? n : gc;
+  Layout<P> L;
+  if (int rc = L.carve(chunk)) return rc;
+  for (size_t o = 0; o < n; o += chunk) {
+    const int m = (int)(n - o < chunk ? n - o : chunk);
+    const uint8_t* c = ct + o * P::CTB;
+    const uint8_t* s = dk + o * P::SKB;
+    RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, P::SKB, L.small));
+    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, P::SKB, L.small));
+    if (int rc = expand_matrix<P, false>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    RUN("k_enc_arith_cmp", st,
+        launch_enc_arith<P, true>(st, m, s + P::PVB, P::SKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, const_cast<uint8_t*>(c)));
+    RUN("k_ml_post_dec", st, k_ml_post_dec<P><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, P::SKB, ss + o * 32));
+  }
+  return 0;
+}
+
+template <class P>
+int ml_check_dev(size_t n, const uint8_t* key, int is_dk, uint32_t* flags, hipStream_t st) {
+  if (is_dk) RUN("k_ml_check", st, k_ml_check<P, true><<<blocks(n, 256), 256, 0, st>>>((int)n, key, flags));
+  else RUN("k_ml_check", st, k_ml_check<P, false><<<blocks(n, 256), 256, 0, st>>>((int)n, key, flags));
+  return 0;
 }
 
 // ---- decapsulation that allocates nothing (include/kyber_batch.h: kyber_batch_dec_dev_noalloc) ----
@@ -808,6 +884,43 @@ int kex_ake_sharedA_host(size_t n, uint8_t* key, const uint8_t* recv, const uint
                      [&](uint8_t** d) { return kex_ake_sharedA_dev<P, N90>(n, d[0], d[1], d[2], d[3], d[4], nullptr); });
 }
 
+template <class P>
+int ml_keypair_host(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins) {
+  Coins c(coins, n * 64);
+  return host_pipeline(n, {{c.p, 64, false}}, {{ek, P::PKB}, {dk, P::SKB}}, [](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+    return ml_keypair_dev<P>(m, out[0], out[1], in[0], st);
+  });
+}
+template <class P>
+int ml_enc_host(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins) {
+  Coins c(coins, n * 32);
+  return host_pipeline(n, {{ek, P::PKB, false}, {c.p, 32, false}}, {{ct, P::CTB}, {ss, 32}},
+                       [](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) { return ml_enc_dev<P>(m, out[0], out[1], in[0], in[1], st); });
+}
+template <class P>
+int ml_dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk) {
+  return host_pipeline(n, {{ct, P::CTB, false}, {dk, P::SKB, false}}, {{ss, 32}},
+                       [](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) { return ml_dec_dev<P>(m, out[0], in[0], in[1], st); });
+}
+template <class P>
+int ml_check_host(size_t n, const uint8_t* key, int is_dk, uint32_t* flags) {
+  const size_t per = is_dk ? P::SKB : P::PKB;
+  return host_pipeline(n, {{key, per, false}}, {{reinterpret_cast<uint8_t*>(flags), 4}},
+                       [is_dk](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+                         return ml_check_dev<P>(m, in[0], is_dk, reinterpret_cast<uint32_t*>(out[0]), st);
+                       });
+}
+
+#define DISPATCH_ML(K, FN, ...)                          \
+  do {                                                   \
+    switch (K) {                                         \
+      case 2: return FN<Par<2>>(__VA_ARGS__);            \
+      case 3: return FN<Par<3>>(__VA_ARGS__);            \
+      case 4: return FN<Par<4>>(__VA_ARGS__);            \
+      default: return KYBER_HIP_EINVAL;                  \
+    }                                                    \
+  } while (0)
+
 // dispatch on the run-time parameter set
 #define DISPATCH(K, NINETIES, FN, ...)                                   \
   do {                                                                    \
@@ -974,6 +1087,53 @@ int kyber_batch_kex_ake_sharedA_dev(int k, int nineties, size_t n, uint8_t* key,
   KEX_PRECHECK(key && recv && tk && sk && ska);
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, kex_ake_sharedA_dev, n, key, recv, tk, sk, ska, st);
+}
+
+// ---- ML-KEM (FIPS 203), include/mlkem_batch.h ----
+int mlkem_batch_keypair(int k, size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins) {
+  if (!ek || !dk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_keypair_host, n, ek, dk, coins);
+}
+int mlkem_batch_encaps(int k, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins) {
+  if (!ct || !ss || !ek || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_enc_host, n, ct, ss, ek, coins);
+}
+int mlkem_batch_decaps(int k, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk) {
+  if (!ss || !ct || !dk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_dec_host, n, ss, ct, dk);
+}
+int mlkem_batch_keypair_dev(int k, size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, void* stream) {
+  if (!ek || !dk || !coins || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_keypair_dev, n, ek, dk, coins, static_cast<hipStream_t>(stream));
+}
+int mlkem_batch_encaps_dev(int k, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins, void* stream) {
+  if (!ct || !ss || !ek || !coins || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_enc_dev, n, ct, ss, ek, coins, static_cast<hipStream_t>(stream));
+}
+int mlkem_batch_decaps_dev(int k, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, void* stream) {
+  if (!ss || !ct || !dk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_dec_dev, n, ss, ct, dk, static_cast<hipStream_t>(stream));
+}
+int mlkem_batch_check_ek(int k, size_t n, const uint8_t* ek, uint32_t* flags) {
+  if (!ek || !flags || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_check_host, n, ek, 0, flags);
+}
+int mlkem_batch_check_dk(int k, size_t n, const uint8_t* dk, uint32_t* flags) {
+  if (!dk || !flags || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_check_host, n, dk, 1, flags);
+}
+int mlkem_batch_check_dev(int k, size_t n, const uint8_t* key, int is_dk, uint32_t* flags, void* stream) {
+  if (!key || !flags || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  DISPATCH_ML(k, ml_check_dev, n, key, is_dk, flags, static_cast<hipStream_t>(stream));
 }
 
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, const uint8_t* seeds, int transposed, void* stream) {

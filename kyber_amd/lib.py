@@ -70,6 +70,15 @@ def library():
         "kyber_batch_keypair_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
         "kyber_batch_enc_mgpu": [ci, ci, sz, u8p, u8p, u8p, u8p, ci, vp],
         "kyber_batch_dec_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
+        "mlkem_batch_keypair": [ci, sz, u8p, u8p, u8p],
+        "mlkem_batch_encaps": [ci, sz, u8p, u8p, u8p, u8p],
+        "mlkem_batch_decaps": [ci, sz, u8p, u8p, u8p],
+        "mlkem_batch_keypair_dev": [ci, sz, u8p, u8p, u8p, vp],
+        "mlkem_batch_encaps_dev": [ci, sz, u8p, u8p, u8p, u8p, vp],
+        "mlkem_batch_decaps_dev": [ci, sz, u8p, u8p, u8p, vp],
+        "mlkem_batch_check_ek": [ci, sz, u8p, u8p],
+        "mlkem_batch_check_dk": [ci, sz, u8p, u8p],
+        "mlkem_batch_check_dev": [ci, sz, u8p, ci, u8p, vp],
         "kyber_batch_keypair_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_enc_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
@@ -333,6 +342,83 @@ class KyberHip:
                                                    _tptr(seeds, n * 32, "seeds"), int(bool(transposed)),
                                                    _torch_stream()), "kyber_batch_gen_matrix_dev")
         return mat
+
+
+class MlKemHip:
+    """ML-KEM (FIPS 203) mode, include/mlkem_batch.h: the *_internal algorithms, batched.
+    Not in the reference; parity unpinned (see the header).  k = 2, 3, 4."""
+
+    def __init__(self, k=3):
+        if k not in (2, 3, 4):
+            raise ValueError("k must be 2, 3 or 4")
+        self.k = k
+        self.ek_bytes, self.dk_bytes, self.ct_bytes = sizes(k)
+        self.lib = library()
+
+    def keypair(self, coins):
+        coins = np.ascontiguousarray(coins, dtype=np.uint8).reshape(-1, 64)
+        n = coins.shape[0]
+        ek, dk = np.empty((n, self.ek_bytes), np.uint8), np.empty((n, self.dk_bytes), np.uint8)
+        _check(self.lib.mlkem_batch_keypair(self.k, n, _ptr(ek), _ptr(dk), _ptr(coins)), "mlkem_batch_keypair")
+        return ek, dk
+
+    def encaps(self, ek, coins):
+        ek = np.ascontiguousarray(ek, dtype=np.uint8).reshape(-1, self.ek_bytes)
+        n = ek.shape[0]
+        coins = _np_u8(np.asarray(coins).reshape(-1, 32), (n, 32), "coins")
+        ct, ss = np.empty((n, self.ct_bytes), np.uint8), np.empty((n, 32), np.uint8)
+        _check(self.lib.mlkem_batch_encaps(self.k, n, _ptr(ct), _ptr(ss), _ptr(ek), _ptr(coins)), "mlkem_batch_encaps")
+        return ct, ss
+
+    def decaps(self, ct, dk):
+        ct = np.ascontiguousarray(ct, dtype=np.uint8).reshape(-1, self.ct_bytes)
+        n = ct.shape[0]
+        dk = _np_u8(np.asarray(dk).reshape(-1, self.dk_bytes), (n, self.dk_bytes), "dk")
+        ss = np.empty((n, 32), np.uint8)
+        _check(self.lib.mlkem_batch_decaps(self.k, n, _ptr(ss), _ptr(ct), _ptr(dk)), "mlkem_batch_decaps")
+        return ss
+
+    def check_ek(self, ek):
+        ek = np.ascontiguousarray(ek, dtype=np.uint8).reshape(-1, self.ek_bytes)
+        flags = np.empty(ek.shape[0], np.uint32)
+        _check(self.lib.mlkem_batch_check_ek(self.k, ek.shape[0], _ptr(ek), _ptr(flags)), "mlkem_batch_check_ek")
+        return flags
+
+    def check_dk(self, dk):
+        dk = np.ascontiguousarray(dk, dtype=np.uint8).reshape(-1, self.dk_bytes)
+        flags = np.empty(dk.shape[0], np.uint32)
+        _check(self.lib.mlkem_batch_check_dk(self.k, dk.shape[0], _ptr(dk), _ptr(flags)), "mlkem_batch_check_dk")
+        return flags
+
+    def keypair_dev(self, coins):
+        import torch
+        n = coins.numel() // 64
+        ek = torch.empty((n, self.ek_bytes), dtype=torch.uint8, device=coins.device)
+        dk = torch.empty((n, self.dk_bytes), dtype=torch.uint8, device=coins.device)
+        if n:
+            _check(self.lib.mlkem_batch_keypair_dev(self.k, n, _tptr(ek, n * self.ek_bytes, "ek"), _tptr(dk, n * self.dk_bytes, "dk"),
+                                                    _tptr(coins, n * 64, "coins"), _torch_stream()), "mlkem_batch_keypair_dev")
+        return ek, dk
+
+    def encaps_dev(self, ek, coins):
+        import torch
+        n = coins.numel() // 32
+        ct = torch.empty((n, self.ct_bytes), dtype=torch.uint8, device=ek.device)
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=ek.device)
+        if n:
+            _check(self.lib.mlkem_batch_encaps_dev(self.k, n, _tptr(ct, n * self.ct_bytes, "ct"), _tptr(ss, n * 32, "ss"),
+                                                   _tptr(ek, n * self.ek_bytes, "ek"), _tptr(coins, n * 32, "coins"), _torch_stream()),
+                   "mlkem_batch_encaps_dev")
+        return ct, ss
+
+    def decaps_dev(self, ct, dk):
+        import torch
+        n = ct.numel() // self.ct_bytes
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device)
+        if n:
+            _check(self.lib.mlkem_batch_decaps_dev(self.k, n, _tptr(ss, n * 32, "ss"), _tptr(ct, n * self.ct_bytes, "ct"),
+                                                   _tptr(dk, n * self.dk_bytes, "dk"), _torch_stream()), "mlkem_batch_decaps_dev")
+        return ss
 
 
 def profile_enable(on):

@@ -601,12 +601,12 @@ void ko_poly_tomsg(uint8_t msg[32], const int16_t a[256])
 /* ------------------------------------------------------------------ */
 #define KMAX 4
 
-static void cpa_keypair(const ko_params *p, uint8_t *pk, uint8_t *sk, const uint8_t d[32])
+static void cpa_keypair_seeded(const ko_params *p, uint8_t *pk, uint8_t *sk, const uint8_t *gin, size_t ginlen)
 {
   const int k = p->k;
   uint8_t g[64];
   int16_t a[KMAX * KMAX * 256], s[KMAX * 256], e[KMAX * 256], t[256];
-  hash_g(p, g, d, 32);                      /* rho = g[0..32), sigma = g[32..64) */
+  hash_g(p, g, gin, ginlen);                /* rho = g[0..32), sigma = g[32..64) */
   ko_gen_matrix(p, a, g, 0, NULL);
   for (int i = 0; i < k; i++) ko_getnoise(p, p->eta1, s + 256 * i, g + 32, (uint8_t)i);
   for (int i = 0; i < k; i++) ko_getnoise(p, p->eta1, e + 256 * i, g + 32, (uint8_t)(k + i));
@@ -620,6 +620,8 @@ static void cpa_keypair(const ko_params *p, uint8_t *pk, uint8_t *sk, const uint
   }
   memcpy(pk + 384 * k, g, 32);
 }
+
+static void cpa_keypair(const ko_params *p, uint8_t *pk, uint8_t *sk, const uint8_t d[32]) { cpa_keypair_seeded(p, pk, sk, d, 32); }
 
 static void cpa_enc(const ko_params *p, uint8_t *ct, const uint8_t m[32], const uint8_t *pk, const uint8_t coins[32])
 {
@@ -699,6 +701,61 @@ void ko_kem_dec(const ko_params *p, uint8_t *ss, const uint8_t *ct, const uint8_
   for (int i = 0; i < 32; i++) kr[i] ^= mask & (kr[i] ^ z[i]);
   kdf(p, ss, kr);
 }
+
+/* ------------------------------------------------------------------ */
+/* ML-KEM (FIPS 203) -- NOT in the reference, PARITY UNPINNED.          */
+/* Restated from the published standard: algorithms 13-15 (K-PKE) are   */
+/* the functions above (ref/indcpa.c:205-329) except that KeyGen hashes */
+/* d || k; algorithms 16-18 are the three functions below.  Checked     */
+/* only against tests/mlkem_model.py, an independent reading of the     */
+/* same text; no official vectors are available offline.                */
+/* ------------------------------------------------------------------ */
+void ko_mlkem_keypair(const ko_params *p, uint8_t *ek, uint8_t *dk, const uint8_t coins[64])
+{ /* ML-KEM.KeyGen_internal(d, z), FIPS 203 algorithm 16 */
+  const size_t pkb = ko_pk_bytes(p), cpa = polyvec_bytes(p);
+  uint8_t gin[33];
+  memcpy(gin, coins, 32);
+  gin[32] = (uint8_t)p->k;                                  /* algorithm 13 line 1: G(d || k) */
+  cpa_keypair_seeded(p, ek, dk, gin, 33);
+  memcpy(dk + cpa, ek, pkb);
+  ko_sha3_256(dk + cpa + pkb, ek, pkb);
+  memcpy(dk + cpa + pkb + 32, coins + 32, 32);
+}
+
+void ko_mlkem_enc(const ko_params *p, uint8_t *ct, uint8_t *ss, const uint8_t *ek, const uint8_t m[32])
+{ /* ML-KEM.Encaps_internal(ek, m), algorithm 17 */
+  uint8_t buf[64], kr[64];
+  memcpy(buf, m, 32);
+  ko_sha3_256(buf + 32, ek, ko_pk_bytes(p));
+  ko_sha3_512(kr, buf, 64);                                 /* (K, r) = G(m || H(ek)) */
+  cpa_enc(p, ct, m, ek, kr + 32);
+  memcpy(ss, kr, 32);
+}
+
+void ko_mlkem_dec(const ko_params *p, uint8_t *ss, const uint8_t *ct, const uint8_t *dk)
+{ /* ML-KEM.Decaps_internal(dk, c), algorithm 18 */
+  const size_t pkb = ko_pk_bytes(p), ctb = ko_ct_bytes(p), cpa = polyvec_bytes(p);
+  const uint8_t *ek = dk + cpa, *h = ek + pkb, *z = h + 32;
+  uint8_t buf[64], kr[64], cmp[4 * 352 + 160], jin[32 + 4 * 352 + 160], kbar[32];
+  uint8_t diff = 0;
+  cpa_dec(p, buf, ct, dk);
+  memcpy(buf + 32, h, 32);
+  ko_sha3_512(kr, buf, 64);                                 /* (K', r') = G(m' || h) */
+  memcpy(jin, z, 32);
+  memcpy(jin + 32, ct, ctb);
+  ko_shake256(kbar, 32, jin, 32 + ctb);                     /* Kbar = J(z || c) */
+  cpa_enc(p, cmp, buf, ek, kr + 32);
+  for (size_t i = 0; i < ctb; i++) diff |= ct[i] ^ cmp[i];
+  uint8_t mask = (uint8_t)-(uint8_t)(diff != 0);
+  for (int i = 0; i < 32; i++) ss[i] = kr[i] ^ (mask & (kr[i] ^ kbar[i]));
+}
+
+void ko_mlkem_batch_keypair(const ko_params *p, size_t n, uint8_t *ek, uint8_t *dk, const uint8_t *coins)
+{ for (size_t i = 0; i < n; i++) ko_mlkem_keypair(p, ek + i * ko_pk_bytes(p), dk + i * ko_sk_bytes(p), coins + 64 * i); }
+void ko_mlkem_batch_enc(const ko_params *p, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *ek, const uint8_t *coins)
+{ for (size_t i = 0; i < n; i++) ko_mlkem_enc(p, ct + i * ko_ct_bytes(p), ss + 32 * i, ek + i * ko_pk_bytes(p), coins + 32 * i); }
+void ko_mlkem_batch_dec(const ko_params *p, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *dk)
+{ for (size_t i = 0; i < n; i++) ko_mlkem_dec(p, ss + 32 * i, ct + i * ko_ct_bytes(p), dk + i * ko_sk_bytes(p)); }
 
 /* ------------------------------------------------------------------ */
 /* key exchange, ref/kex.c:6-54 (coins replace the randombytes draws of   */

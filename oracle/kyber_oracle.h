@@ -61,6 +61,14 @@ void ko_kex_ake_sharedB(const ko_params *p, uint8_t *send, uint8_t *k, const uin
                         const uint8_t coins[64]);
 void ko_kex_ake_sharedA(const ko_params *p, uint8_t *k, const uint8_t *recv, const uint8_t *tk, const uint8_t *sk, const uint8_t *ska);
 
+/* ML-KEM (FIPS 203) internal algorithms 16-18 -- not in the reference, parity unpinned (see kyber_oracle.c) */
+void ko_mlkem_keypair(const ko_params *p, uint8_t *ek, uint8_t *dk, const uint8_t coins[64]);
+void ko_mlkem_enc(const ko_params *p, uint8_t *ct, uint8_t *ss, const uint8_t *ek, const uint8_t m[32]);
+void ko_mlkem_dec(const ko_params *p, uint8_t *ss, const uint8_t *ct, const uint8_t *dk);
+void ko_mlkem_batch_keypair(const ko_params *p, size_t n, uint8_t *ek, uint8_t *dk, const uint8_t *coins);
+void ko_mlkem_batch_enc(const ko_params *p, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *ek, const uint8_t *coins);
+void ko_mlkem_batch_dec(const ko_params *p, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *dk);
+
 void ko_batch_keypair(const ko_params *p, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins);
 void ko_batch_enc(const ko_params *p, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins);
 void ko_batch_dec(const ko_params *p, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk);

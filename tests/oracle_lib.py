@@ -155,6 +155,36 @@ class Oracle:
         self.lib.ko_batch_dec(ctypes.byref(p), n, _p(ss), _p(ct), _p(sk))
         return ss
 
+    # ---- ML-KEM (FIPS 203) internal algorithms; parity unpinned, see oracle/kyber_oracle.c ----
+    def mlkem_keypair(self, k, coins):
+        p = self.params(k)
+        coins = np.ascontiguousarray(coins, np.uint8).reshape(-1, 64)
+        n = coins.shape[0]
+        pkb, skb, _ = self.sizes(k)
+        ek, dk = np.empty((n, pkb), np.uint8), np.empty((n, skb), np.uint8)
+        self.lib.ko_mlkem_batch_keypair(ctypes.byref(p), ctypes.c_size_t(n), _p(ek), _p(dk), _p(coins))
+        return ek, dk
+
+    def mlkem_enc(self, k, ek, coins):
+        p = self.params(k)
+        pkb, _, ctb = self.sizes(k)
+        ek = np.ascontiguousarray(ek, np.uint8).reshape(-1, pkb)
+        coins = np.ascontiguousarray(coins, np.uint8).reshape(-1, 32)
+        n = ek.shape[0]
+        ct, ss = np.empty((n, ctb), np.uint8), np.empty((n, 32), np.uint8)
+        self.lib.ko_mlkem_batch_enc(ctypes.byref(p), ctypes.c_size_t(n), _p(ct), _p(ss), _p(ek), _p(coins))
+        return ct, ss
+
+    def mlkem_dec(self, k, ct, dk):
+        p = self.params(k)
+        _, skb, ctb = self.sizes(k)
+        ct = np.ascontiguousarray(ct, np.uint8).reshape(-1, ctb)
+        dk = np.ascontiguousarray(dk, np.uint8).reshape(-1, skb)
+        n = ct.shape[0]
+        ss = np.empty((n, 32), np.uint8)
+        self.lib.ko_mlkem_batch_dec(ctypes.byref(p), ctypes.c_size_t(n), _p(ss), _p(ct), _p(dk))
+        return ss
+
     def gen_matrix(self, k, seed, transposed, nineties=0):
         p = self.params(k, nineties)
         seed = np.ascontiguousarray(seed, np.uint8)

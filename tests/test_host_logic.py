@@ -17,6 +17,8 @@ def _declared_symbols():
     names = set()
     batch = open(os.path.join(ROOT, "include", "kyber_batch.h")).read()
     names.update(re.findall(r"^\s*(?:int|size_t|void|const char \*)\s*\*?(\w+)\(", batch, re.M))
+    ml = open(os.path.join(ROOT, "include", "mlkem_batch.h")).read()
+    names.update(re.findall(r"^\s*int\s+(\w+)\(", ml, re.M))
     for s in re.findall(r"^KYBER_HIP_DECLARE_SET\((\w+)\)", batch, re.M):
         names.update("%s_batch_%s" % (s, op) for op in ("keypair", "enc", "dec"))
     api = open(os.path.join(ROOT, "include", "kyber_api.h")).read()
