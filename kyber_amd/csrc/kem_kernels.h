@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_et
 //
 // Each lane appends its accepted values to a private row of an LDS staging
 // tile ("always store, advance only on accept": no divergent branch) and then
-// copies the row to its polynomial with 16-byte stores (drain_private).  Entries
+// copies whole 64-byte lines of the row to its polynomial with 16-byte stores.  Entries
 // that still miss coefficients after three blocks (P ~ 0.9 % each) are handed
 // to k_sample_matrix_tail through a queue instead of keeping their wavefront
 // squeezing.
@@ -369,43 +369,19 @@ __device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& wa
   }
 }
 
-// Lane-private drain: every lane copies its own staging row to its own
-// polynomial (rows are private, so no cross-lane traffic and no readlanes).
-// Up to three single dwords bring the destination to a 16-byte boundary, the
-// rest leaves as aligned 16-byte stores read from the row at the matching
-// offset.  An aligned store may carry up to three dwords past the lane's
-// count; they lie inside the same polynomial (whose end is 16-byte aligned) and
-// are overwritten by the next piece or by the tail kernel.
-template <int SDW>
-__device__ __forceinline__ int drain_private(uint32_t* row, long job, int c0, int c1, uint32_t* mat32) {
-  const int d0 = c0 >> 1;
-  const int nd = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0 : 0;
-  const int head = min((4 - (d0 & 3)) & 3, nd);
-  uint32_t* dst = mat32 + job * 128 + d0;
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-    if (r < head) dst[r] = row[r];
-  const uint32_t* src = row + head;
-  uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
-  const int body = nd - head;
-#pragma unroll
-  for (int q = 0; q < (SDW + 3) / 4; q++)
-    if (4 * q < body) dst4[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
-  if (c0 < 256 && (c1 & 1)) {
-    uint16_t* h = reinterpret_cast<uint16_t*>(row);
-    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
-  }
-  return c0 < 256 ? c1 : c0;
-}
-
-// A 168-byte block is parsed and drained in MAT_PARTS parts, so the staging row
-// of a lane holds 1 carry slot + 112/MAT_PARTS candidates + 1 spill slot.  Two
-// parts: 29 dwords per lane, 29 KB per workgroup, five workgroups per CU (the
-// whole-block tile of 57 dwords allowed two and left the drain's store latency
-// exposed).
+// A 168-byte block is parsed and drained in two halves.  The staging row of a lane always
+// STARTS at a 64-byte line of its polynomial: after a half-block's parse only whole lines (32
+// coefficients) leave, as aligned 16-byte stores, and the remainder (< 32 coefficients) moves to
+// the front of the row for the next half-block.  Every line of the matrix is written exactly
+// once, whole, and the drain needs no head / tail alignment logic.  (Round 1 drained whatever a
+// half-block produced, ragged ~90-byte pieces at 4-byte alignment: most lines were written twice,
+// 1.41x write traffic, and the kernel was 3 % slower although its rows were smaller.)
+// Row = 31 carried + 56 candidates + 1 spill slot, padded to an odd dword stride: 45 dwords per
+// lane, 46 KB per workgroup, three workgroups per CU (the permutation needs two wavefronts per
+// SIMD for its full rate, tools/microbench/keccak_rate.hip).
 constexpr int MAT_PARTS = 2;
 constexpr int MAT_GROUPS = 56 / MAT_PARTS;          // 3-byte groups per part
-constexpr int MAT_STAGE_DW = (2 * MAT_GROUPS + 2) / 2;
+constexpr int MAT_STAGE_DW = 45;
 
 // Tail queue: dword 0 = number of records pushed (may exceed the capacity),
 // records of 64 dwords from dword 64: sponge state (50), entry index, count.
@@ -426,14 +402,15 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
   }
 }
 
-template <class P, int ABLATE = 0>  // ABLATE != 0 only in tools/microbench (1: no drain, 2: no parse either, 3: no drain, conflict-free staging stores, 4: no drain, no staging stores)
+// ABLATE != 0 only in tools/microbench (1: no drain; 2: no parse either; 3: no drain, staging
+// stores at cursor-independent, conflict-free addresses; 4: no drain, no staging stores)
+template <class P, int ABLATE = 0>
 __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
-                                                       int transposed, int16_t* __restrict__ mat,
-                                                       uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  __shared__ uint32_t stage[4 * 64 * MAT_STAGE_DW + 8];  // + 8: the drain reads whole 16-byte groups from a row
+                                                          int transposed, int16_t* __restrict__ mat,
+                                                          uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+  __shared__ uint32_t stage[4 * 64 * MAT_STAGE_DW + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long job0 = (long)blockIdx.x * 256 + wave * 64;  // first job of this wavefront
-  const long job = job0 + lane;
+  const long job = (long)blockIdx.x * 256 + wave * 64 + lane;
   const bool valid = job < njobs;
   const long jc = valid ? job : (long)njobs - 1;
   const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
@@ -445,13 +422,14 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   keccak_zero(A);
 #pragma unroll
   for (int w = 0; w < 4; w++) A[w] = seed[w];
-  A[4].lo = x | y << 8 | 0x1F0000u;  // rho || x || y || pad    ref/symmetric-shake.c:25-29
+  A[4].lo = x | y << 8 | 0x1F0000u;
   A[20].hi = 0x80000000u;
 
   uint32_t* row = stage + (wave * 64 + lane) * MAT_STAGE_DW;
   const uint32_t row_addr = lds_addr(row);
-  uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
-  int ctr = valid ? 0 : 256;
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(mat) + job * 128;
+  int ctr = valid ? 0 : 256;  // coefficients already in memory: a multiple of 32 until the entry is parked
+  int pend = 0;               // coefficients waiting at the front of the row, < 32
   int blk = 0;
 
   while (__any(ctr < 256)) {
@@ -461,8 +439,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
     auto part = [&](auto first) {
       constexpr int G0 = decltype(first)::value;
-      // slot 0 of the row may hold a carried coefficient (ctr odd): start after it
-      const uint32_t w0 = row_addr + 2u * (ctr & 1);
+      const uint32_t w0 = row_addr + 2u * pend;
       uint32_t waddr = w0;
       if constexpr (ABLATE == 3 || ABLATE == 4) {
         parse_range<G0, G0 + MAT_GROUPS, 42, true>(H, waddr, ABLATE == 3 ? row_addr : 0u);
@@ -473,26 +450,42 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
         for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
         waddr += 2 * (91 / MAT_PARTS);
       }
-      const int c0 = ctr;
-      const int c1 = c0 + (int)((waddr - w0) >> 1);
-      if constexpr (ABLATE == 0) ctr = drain_private<MAT_STAGE_DW>(row, job, c0, c1, out32);
-      else ctr = c0 < 256 ? c1 : c0;
+      const int cnt = pend + (int)((waddr - w0) >> 1);                 // <= 31 + 56
+      const bool live = ctr < 256;
+      const int nl = !live ? 0 : (ctr + cnt >= 256 ? (256 - ctr) >> 5 : cnt >> 5);  // whole lines that leave now: 0..2 (last round: up to 8 - ctr/32)
+      uint4* dst = reinterpret_cast<uint4*>(out32 + (ctr >> 1));
+      if constexpr (ABLATE == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < 4 * nl) dst[q] = make_uint4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+      }
+      ctr += 32 * nl;
+      pend = (live && ctr < 256) ? cnt - 32 * nl : 0;
+      if (nl > 0 && pend > 0) {  // the remainder moves to the front (source and destination never overlap)
+        const uint32_t* src = row + 16 * nl;
+#pragma unroll
+        for (int d = 0; d < 16; d += 2) {
+          const uint32_t a = src[d], b = src[d + 1];
+          row[d] = a;
+          row[d + 1] = b;
+        }
+      }
     };
     part(std::integral_constant<int, 0>{});
-    if constexpr (MAT_PARTS == 2) part(std::integral_constant<int, MAT_GROUPS>{});
-    // Three blocks complete 99.1 % of the entries, but 41 % of the wavefronts
-    // hold at least one that is still short.  Those entries park their sponge in
-    // the tail queue (k_sample_matrix_tail finishes them, densely packed) instead
-    // of keeping 64 lanes squeezing for one; a full queue just leaves them here.
+    part(std::integral_constant<int, MAT_GROUPS>{});
     if (++blk == MAT_MAIN_BLOCKS && tailq != nullptr && ctr < 256) {
       const uint32_t slot = atomicAdd(tailq, 1u);
       if (slot < tail_cap) {
+        // parked entries hand over ctr + pend coefficients in memory: flush the pending ones (a
+        // partial line; an odd last coefficient travels in the low half of its dword)
+        for (int d = 0; 2 * d < pend; d++) out32[(ctr >> 1) + d] = row[d];
         uint32_t* r = tailq + TAILQ_HDR_DW + (size_t)slot * TAILQ_REC_DW;
 #pragma unroll
         for (int w = 0; w < 24; w += 2)
           *reinterpret_cast<uint4*>(r + 2 * w) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
-        *reinterpret_cast<uint4*>(r + 48) = make_uint4(A[24].lo, A[24].hi, (uint32_t)job, (uint32_t)ctr);
+        *reinterpret_cast<uint4*>(r + 48) = make_uint4(A[24].lo, A[24].hi, (uint32_t)job, (uint32_t)(ctr + pend));
         ctr = 256;
+        pend = 0;
       }
     }
   }

@@ -185,6 +185,36 @@ constexpr int XOF90_BLOCKS = 3;                                 // AES blocks pe
 constexpr int XOF90_GROUPS = 16 * XOF90_BLOCKS / 3;             // 3-byte groups per step
 constexpr int STAGE90_DW = (2 * XOF90_GROUPS + 2) / 2;          // 1 carry slot + candidates + 1 spill, in dwords
 
+// Lane-private drain: every lane copies its own staging row to its own
+// polynomial (rows are private, so no cross-lane traffic and no readlanes).
+// Up to three single dwords bring the destination to a 16-byte boundary, the
+// rest leaves as aligned 16-byte stores read from the row at the matching
+// offset.  An aligned store may carry up to three dwords past the lane's
+// count; they lie inside the same polynomial (whose end is 16-byte aligned) and
+// are overwritten by the next piece or by the tail kernel.
+template <int SDW>
+__device__ __forceinline__ int drain_private(uint32_t* row, long job, int c0, int c1, uint32_t* mat32) {
+  const int d0 = c0 >> 1;
+  const int nd = c0 < 256 ? (((c1 < 256 ? c1 : 256) + 1) >> 1) - d0 : 0;
+  const int head = min((4 - (d0 & 3)) & 3, nd);
+  uint32_t* dst = mat32 + job * 128 + d0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    if (r < head) dst[r] = row[r];
+  const uint32_t* src = row + head;
+  uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
+  const int body = nd - head;
+#pragma unroll
+  for (int q = 0; q < (SDW + 3) / 4; q++)
+    if (4 * q < body) dst4[q] = make_uint4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+  if (c0 < 256 && (c1 & 1)) {
+    uint16_t* h = reinterpret_cast<uint16_t*>(row);
+    h[0] = h[(c0 & 1) + (c1 - c0) - 1];
+  }
+  return c0 < 256 ? c1 : c0;
+}
+
+
 template <class P>
 __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                          int transposed, int16_t* __restrict__ mat) {

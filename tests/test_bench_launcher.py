@@ -3,6 +3,7 @@ outside torchrun) and also runs as one rank under torchrun.  CPU rehearsal:
 gloo, a stand-in engine (tests/bench_stub_engine.py), two ranks."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,6 +11,12 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def _env():
@@ -39,13 +46,13 @@ def test_gpus_2_launches_two_ranks():
 def test_one_rank_under_torchrun_and_world_mismatch():
     base = [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--batch", "8", "--device", "cpu", "--no-cpu-baseline"]
     run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731"]
+           "--master-port", str(_free_port())]
     r = subprocess.run(run + base + ["--gpus", "2"], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert _line(r.stdout)["n_gpus"] == 2
     # a world that differs from --gpus is refused instead of printing a mislabelled line
     env = _env()
-    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29732")
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable] + base + ["--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode != 0 and b"{" not in r.stdout
 
