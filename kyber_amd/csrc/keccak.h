@@ -70,18 +70,41 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 }
 
 // One round, A -> E (separate arrays so pi is pure renaming).
+// KY_KECCAK_PHASED (tools/microbench only): 1 = one instruction class per phase; 2 = and the wavefronts
+// of a workgroup enter every phase together; 3 = ... enter every round together; 4 = every second round
+#if defined(KY_KECCAK_PHASED)
+#define KY_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if KY_KECCAK_PHASED == 2
+#define KY_PHASE() KY_SYNC()
+#else
+#define KY_PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#else
+#define KY_PHASE()
+#endif
 __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25], uint64_t rc) {
-  u64p C[5], R[5], B[25];
+  u64p C[5], R[5], T[25], B[25];
+#if defined(KY_KECCAK_PHASED) && KY_KECCAK_PHASED == 3
+  KY_SYNC();
+#endif
 #pragma unroll
   for (int x = 0; x < 5; x++) C[x] = xor3(xor3(A[x], A[x + 5], A[x + 10]), A[x + 15], A[x + 20]);
+  KY_PHASE();
 #pragma unroll
   for (int x = 0; x < 5; x++) R[x] = rol<1>(C[x]);
-    // theta-apply fused with rho/pi: B[y, 2x+3y] = rol(A[x,y] ^ C[x-1] ^ rol1(C[x+1]), rho(x,y))
-#define KY_RPI(x, y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol<keccak_rho(x, y)>(xor3(A[x + 5 * y], C[(x + 4) % 5], R[(x + 1) % 5]));
+  KY_PHASE();
+  // theta-apply, then rho/pi: B[y, 2x+3y] = rol(A[x,y] ^ C[x-1] ^ rol1(C[x+1]), rho(x,y))
+#pragma unroll
+  for (int y = 0; y < 5; y++)
+#pragma unroll
+    for (int x = 0; x < 5; x++) T[x + 5 * y] = xor3(A[x + 5 * y], C[(x + 4) % 5], R[(x + 1) % 5]);
+  KY_PHASE();
+#define KY_RPI(x, y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol<keccak_rho(x, y)>(T[x + 5 * y]);
 #define KY_RPI_ROW(y) KY_RPI(0, y) KY_RPI(1, y) KY_RPI(2, y) KY_RPI(3, y) KY_RPI(4, y)
   KY_RPI_ROW(0) KY_RPI_ROW(1) KY_RPI_ROW(2) KY_RPI_ROW(3) KY_RPI_ROW(4)
 #undef KY_RPI_ROW
 #undef KY_RPI
+  KY_PHASE();
 #pragma unroll
   for (int y = 0; y < 5; y++)
 #pragma unroll
@@ -89,12 +112,16 @@ __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25],
       E[x + 5 * y] = chi(B[x + 5 * y], B[(x + 1) % 5 + 5 * y], B[(x + 2) % 5 + 5 * y]);
   E[0].lo ^= (uint32_t)rc;
   E[0].hi ^= (uint32_t)(rc >> 32);
+  KY_PHASE();
 }
 
 __device__ __forceinline__ void keccak_f1600(u64p (&A)[25]) {
   u64p E[25];
 #pragma unroll 1
   for (int r = 0; r < 24; r += 2) {
+#if defined(KY_KECCAK_PHASED) && KY_KECCAK_PHASED == 4
+    KY_SYNC();
+#endif
     keccak_round(A, E, KECCAK_RC[r]);
     keccak_round(E, A, KECCAK_RC[r + 1]);
   }

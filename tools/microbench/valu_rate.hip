@@ -101,6 +101,12 @@ KERNEL(k_mov, A_MOV)
 #define A_MBCNT(n) "v_mbcnt_lo_u32_b32 %" #n ", %" #n ", %8\n"
 #define A_DOT2(n) "v_dot2_i32_i16 %" #n ", %8, %9, %" #n "\n"
 #define A_DOT4(n) "v_dot4_i32_i8 %" #n ", %8, %9, %" #n "\n"
+#define A_ANDLIT(n) "v_and_b32 %" #n ", 0xabc, %" #n "\n"
+#define A_ADDLIT(n) "v_add_u32 %" #n ", 0xfffff2ff, %" #n "\n"
+#define A_ANDINL(n) "v_and_b32 %" #n ", 2, %" #n "\n"
+KERNEL(k_andlit, A_ANDLIT)
+KERNEL(k_addlit, A_ADDLIT)
+KERNEL(k_andinl, A_ANDINL)
 KERNEL(k_cmpcnd, A_CMPCND)
 KERNEL(k_cmp, A_CMP)
 KERNEL(k_cmpaddc, A_CMPADDC)
@@ -158,6 +164,94 @@ KERNEL(k_cvti16hi, A_CVTI16HI)
 KERNEL(k_cvtpkrtz, A_CVTPKRTZ)
 KERNEL(k_cvtub, A_CVTUB)
 
+// 32 v_bitop3_b32 and 32 v_alignbit_b32 per 64 instructions, in runs of RUN: does changing between
+// the full-rate and the half-rate class cost issue cycles?
+template <int RUN>
+__global__ void __launch_bounds__(1024) k_mix(uint32_t* out, unsigned long long* cyc, int iters) {
+  uint32_t r[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = threadIdx.x * (2 * j + 1) + j;
+  uint32_t a = out[threadIdx.x & 63], b = out[(threadIdx.x + 1) & 63];
+  unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 64; u++) {
+      if ((u / RUN) & 1) asm volatile("v_alignbit_b32 %0, %0, %1, 13" : "+v"(r[u % 8]) : "v"(a));
+      else asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[u % 8]) : "v"(a), "v"(b));
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r[0] ^ r[1] ^ r[2] ^ r[3] ^ r[4] ^ r[5] ^ r[6] ^ r[7];
+  unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = rt1 - rt0; }
+}
+
+// 96 instructions per iteration on CH independent dependency chains (CH divides 96): how does the
+// distance between an instruction and the one that consumes its result change the issue rate?
+// OP 0: v_add_u32 (result -> src0), 1: v_add_u32 (result -> src1), 2: v_bitop3_b32, 3: v_alignbit_b32,
+// 4: v_fma_f32
+template <int CH, int OP>
+__global__ void __launch_bounds__(1024) k_dep(uint32_t* out, unsigned long long* cyc, int iters) {
+  uint32_t r[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) r[j] = threadIdx.x * (2 * j + 1) + j;
+  uint32_t a = out[threadIdx.x & 63], b = out[(threadIdx.x + 1) & 63];
+  unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters * 2 / 3; i++) {
+#pragma unroll
+    for (int u = 0; u < 96; u++) {
+      if (OP == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[u % CH]) : "v"(a));
+      if (OP == 1) asm volatile("v_add_u32 %0, %1, %0" : "+v"(r[u % CH]) : "v"(a));
+      if (OP == 2) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[u % CH]) : "v"(a), "v"(b));
+      if (OP == 3) asm volatile("v_alignbit_b32 %0, %0, %1, 13" : "+v"(r[u % CH]) : "v"(a));
+      if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[u % CH]) : "v"(a), "v"(b));
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) x ^= r[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+  unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = rt1 - rt0; }
+}
+// the rejection parse's instruction pattern: per candidate and-literal, add-literal, shift, and-inline,
+// cursor add (the cursor is one serial chain), 8 candidates per block on 8 value registers
+template <bool LIT>
+__global__ void __launch_bounds__(1024) k_parse(uint32_t* out, unsigned long long* cyc, int iters) {
+  uint32_t r[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = threadIdx.x * (2 * j + 1) + j;
+  uint32_t cur = out[threadIdx.x & 63], m = 0xabc, q = 0xfffff2ffu;
+  asm volatile("" : "+v"(m), "+v"(q));
+  unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 12; u++) {   // 12 x 5 = 60 instructions + 4 fill = 64
+      uint32_t d;
+      if (LIT) {
+        asm volatile("v_and_b32 %0, 0xabc, %1" : "=v"(d) : "v"(r[u % 8]));
+        asm volatile("v_add_u32 %0, 0xfffff2ff, %0" : "+v"(d));
+      } else {
+        asm volatile("v_and_b32 %0, %2, %1" : "=v"(d) : "v"(r[u % 8]), "v"(m));
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(d) : "v"(q));
+      }
+      asm volatile("v_lshrrev_b32 %0, 30, %0" : "+v"(d));
+      asm volatile("v_and_b32 %0, 2, %0" : "+v"(d));
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(cur) : "v"(d));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[u]) : "v"(cur));
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r[0] ^ r[1] ^ r[2] ^ r[3] ^ cur;
+  unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = rt1 - rt0; }
+}
+
 typedef void (*kfn)(uint32_t*, unsigned long long*, int);
 struct V { const char* name; kfn f; };
 
@@ -176,6 +270,12 @@ int main() {
             {"v_lshrrev_b32", k_lshr}, {"v_and_b32", k_and}, {"v_sub_u32", k_sub}, {"v_min_u32", k_min}, {"v_med3_i32", k_med3},
             {"v_xor_b32_sdwa", k_xorsdwa}, {"v_add_i16", k_addi16}, {"v_mul_lo_u16", k_mulu16}, {"v_mad_u16", k_madu16},
             {"v_pk_mad_i16", k_pkmad}, {"v_pk_ashrrev_i16", k_pkashr}, {"v_mul_hi_u32", k_mulhiu}, {"v_sad_u32", k_sad},
+            {"v_and_b32 literal", k_andlit}, {"v_add_u32 literal", k_addlit}, {"v_and_b32 inline", k_andinl},
+            #define DEPS(NAME, OP) {NAME " dist 1", k_dep<1, OP>}, {NAME " dist 2", k_dep<2, OP>}, {NAME " dist 3", k_dep<3, OP>}, {NAME " dist 4", k_dep<4, OP>}, \
+            {NAME " dist 6", k_dep<6, OP>}, {NAME " dist 8", k_dep<8, OP>}, {NAME " dist 12", k_dep<12, OP>}, {NAME " dist 16", k_dep<16, OP>},
+            DEPS("add src0", 0) DEPS("add src1", 1) DEPS("bitop3", 2) DEPS("alignbit", 3) DEPS("fma", 4)
+            {"parse mix literal", k_parse<true>}, {"parse mix vgpr", k_parse<false>},
+            {"mix run 1", k_mix<1>}, {"mix run 2", k_mix<2>}, {"mix run 4", k_mix<4>}, {"mix run 8", k_mix<8>}, {"mix run 32", k_mix<32>},
             {"v_bcnt_u32_b32", k_bcnt}, {"v_mbcnt_lo", k_mbcnt}, {"v_dot2_i32_i16", k_dot2}, {"v_dot4_i32_i8", k_dot4}};
   uint32_t* out; unsigned long long* cyc;
   const int nblk = 512;
@@ -183,6 +283,7 @@ int main() {
   CK(hipMalloc(&cyc, nblk * 16));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 2000;  // x 64 instructions
+  { int wk = 0; CK(hipDeviceGetAttribute(&wk, hipDeviceAttributeWallClockRate, 0)); printf("wall clock rate %d kHz\n", wk); }
   printf("per config: memtime ticks per wave-instr per SIMD | shader MHz from memtime/memrealtime | T lane-op/s by wall clock\n");
   for (auto& v : vs) {
     printf("%-18s", v.name);
