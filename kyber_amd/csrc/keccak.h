@@ -70,21 +70,36 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 }
 
 // One round, A -> E (separate arrays so pi is pure renaming).
-// KY_KECCAK_PHASED (tools/microbench only): 1 = one instruction class per phase; 2 = and the wavefronts
-// of a workgroup enter every phase together; 3 = ... enter every round together; 4 = every second round
-#if defined(KY_KECCAK_PHASED)
-#define KY_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#if KY_KECCAK_PHASED == 2
+//
+// Phase lock.  gfx950 issues the logic ops (v_bitop3_b32, 2 cycles per wavefront) and the rotates
+// (v_alignbit_b32, 4 cycles) at those rates only while the wavefronts that share a SIMD issue the same
+// class: mixed streams cost ~0.9 cycle more per rotate whatever the run lengths inside one wavefront
+// (tools/microbench/valu_rate.hip "mix run N"), because the wavefronts drift apart and the SIMD
+// interleaves them.  So a round is cut into five single-class phases (20 + 10 + 50 + 48 + 50
+// instructions) and the wavefronts of a workgroup enter each phase together: kernels that hash run
+// 512-work-item workgroups (SPONGE_WG), two wavefronts per SIMD from one workgroup, two workgroups per
+// CU.  Bare permutation 10.1 -> 11.9 G/s (tools/microbench/keccak_rate.hip, profiles/
+// r02_microbench_keccak_rate.txt; barriers per round or per two rounds instead lose to no barrier).
+// The barrier only aligns issue: no data crosses it, waves that have ended do not count, and a
+// wavefront that runs more permutations than its neighbours pairs its barriers with whoever is left.
+// It is written as asm so that the compiler does not drain the memory counters in front of it.
+constexpr int SPONGE_WG = 512;
+#if defined(KY_KECCAK_PHASED)   // tools/microbench only: 0 = compiler's schedule, 1 = phases without barrier, 2 = product, 3/4 = barrier per round / two rounds
+#define KY_LOCK_MODE KY_KECCAK_PHASED
+#else
+#define KY_LOCK_MODE 2
+#endif
+#define KY_SYNC() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if KY_LOCK_MODE == 2
 #define KY_PHASE() KY_SYNC()
+#elif KY_LOCK_MODE == 0
+#define KY_PHASE()
 #else
 #define KY_PHASE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#else
-#define KY_PHASE()
-#endif
 __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25], uint64_t rc) {
   u64p C[5], R[5], T[25], B[25];
-#if defined(KY_KECCAK_PHASED) && KY_KECCAK_PHASED == 3
+#if KY_LOCK_MODE == 3
   KY_SYNC();
 #endif
 #pragma unroll
@@ -119,7 +134,7 @@ __device__ __forceinline__ void keccak_f1600(u64p (&A)[25]) {
   u64p E[25];
 #pragma unroll 1
   for (int r = 0; r < 24; r += 2) {
-#if defined(KY_KECCAK_PHASED) && KY_KECCAK_PHASED == 4
+#if KY_LOCK_MODE == 4
     KY_SYNC();
 #endif
     keccak_round(A, E, KECCAK_RC[r]);

@@ -62,8 +62,8 @@ __device__ __forceinline__ void st32B(uint8_t* p, const u64p& a, const u64p& b, 
 
 // ------------------------------------------------------------------ FO hashes
 // keypair, before: (rho, sigma) = G(d).                        ref/indcpa.c:215-216
-__global__ void __launch_bounds__(256) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
   ld32B(coins + (size_t)i * 64, d);
@@ -80,9 +80,9 @@ __global__ void __launch_bounds__(256) k_kp_pre(int n, const uint8_t* __restrict
 
 // keypair, after: sk tail = H(pk) || z.                          ref/kem.c:30-32
 template <class P>
-__global__ void __launch_bounds__(256) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  uint8_t* __restrict__ sk) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], z[4];
   keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
@@ -104,9 +104,9 @@ __global__ void __launch_bounds__(64) k_hash_pk(const uint8_t* __restrict__ pk, 
 // encaps, before: m = H(m0); (Kbar, r) = G(m || H(pk)).         ref/kem.c:59-65
 // hpk != null: every instance uses that one precomputed H(pk) (shared key).
 template <class P>
-__global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   ld32B(coins + (size_t)i * 32, m);
@@ -129,9 +129,9 @@ __global__ void __launch_bounds__(256) k_enc_pre(int n, const uint8_t* __restric
 
 // decaps, middle: (Kbar', r') = G(m' || H(pk) from sk).          ref/kem.c:109-111
 template <class P>
-__global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
                                                  uint8_t* __restrict__ small) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   uint8_t* s = small + (size_t)i * SMALL;
@@ -144,9 +144,9 @@ __global__ void __launch_bounds__(256) k_dec_mid(int n, const uint8_t* __restric
 
 // encaps/decaps, after: ss = KDF(Kbar-or-z || H(ct)).            ref/kem.c:71-73, :116-125
 template <class P, bool DEC>
-__global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                               const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], kb[4], h[4];
   keccak_absorb_words<136, 0x06, P::CTB>(A, ct + (size_t)i * P::CTB);
@@ -177,8 +177,8 @@ __global__ void __launch_bounds__(256) k_post(int n, const uint8_t* __restrict__
 // (Decaps_internal: implicit rejection key J(z || c) = SHAKE256(z || c, 32)).
 
 // keypair, before: (rho, sigma) = G(d || k)
-__global__ void __launch_bounds__(256) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
   ld32B(coins + (size_t)i * 64, d);
@@ -195,9 +195,9 @@ __global__ void __launch_bounds__(256) k_ml_kp_pre(int n, int k, const uint8_t* 
 
 // encaps: (K, r) = G(m || H(ek)); the shared secret is K itself
 template <class P>
-__global__ void __launch_bounds__(256) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                     uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   ld32B(coins + (size_t)i * 32, m);
@@ -213,9 +213,9 @@ __global__ void __launch_bounds__(256) k_ml_enc_pre(int n, const uint8_t* __rest
 
 // decaps, after: ss = (c == c') ? K' : J(z || c), selected without a branch
 template <class P>
-__global__ void __launch_bounds__(256) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                                      const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   constexpr int RW = 17, TOTW = 4 + P::CTB / 8, NFULL = TOTW / RW, TAILW = TOTW % RW;
   const uint8_t* c = ct + (size_t)i * P::CTB;
@@ -255,8 +255,8 @@ __global__ void __launch_bounds__(256) k_ml_post_dec(int n, const uint8_t* __res
 //   ek: every 12-bit coefficient of the encoded t^ is below q ("modulus check")
 //   dk: the same for the embedded ek, and H(ek) equals the stored hash ("hash check")
 template <class P, bool DK>
-__global__ void __launch_bounds__(256) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
+  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   const uint8_t* ek = key + (size_t)i * (DK ? P::SKB : P::PKB) + (DK ? P::PVB : 0);
   uint32_t bad = 0;
@@ -287,9 +287,9 @@ __global__ void __launch_bounds__(256) k_ml_check(int n, const uint8_t* __restri
 // binomial map is applied by the consumer in poly layout.
 // ref/symmetric-shake.c:43-51 + ref/poly.c:208-232 (prf part).
 template <class P>
-__global__ void __launch_bounds__(256) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
                                              int seed_off, uint8_t* __restrict__ prf) {
-  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  long gid = (long)blockIdx.x * SPONGE_WG + threadIdx.x;
   if (gid >= (long)n * njobs_per_inst) return;
   int nonce = (int)(gid / n), inst = (int)(gid % n);
   u64p A[25], key[4];
@@ -361,27 +361,64 @@ __device__ __forceinline__ void parse_group(const uint32_t (&H)[N], uint32_t& wa
   if (!(FIXED && fixed == 0)) lds_st16(FIXED ? fixed + 4 * (G % 28) + 2 : waddr, d2);
   waddr += accept_step(d2);
 }
+// Groups G0..G1-1 of the block.  The compiler, left alone, turns the straightforward loop into one
+// serial dependency chain on three registers (extract -> subtract -> shift -> mask -> cursor add ->
+// next extract ...): every instruction then waits for its predecessor, 8 cycles on gfx950
+// (tools/microbench/valu_rate.hip "dist 1"), and a dependency at distance two is the most expensive
+// case of all.  So the candidates and their cursor steps are computed first, as independent
+// instructions, BATCH groups at a time, and only the cursor additions form a chain.
+constexpr int PARSE_BATCH = 7;
+template <int G, int G1, int N>
+__device__ __forceinline__ void parse_extract(const uint32_t (&H)[N], uint32_t* d) {
+  if constexpr (G < G1) {
+    d[0] = field12<24 * G, N>(H);
+    d[1] = field12<24 * G + 12, N>(H);
+    parse_extract<G + 1, G1, N>(H, d + 2);
+  }
+}
 template <int G0, int G1, int N, bool FIXED = false>
 __device__ __forceinline__ void parse_range(const uint32_t (&H)[N], uint32_t& waddr, uint32_t fixed = 0) {
-  if constexpr (G0 < G1) {
-    parse_group<G0, N, FIXED>(H, waddr, fixed);
-    parse_range<G0 + 1, G1, N, FIXED>(H, waddr, fixed);
+  if constexpr (FIXED) {
+    if constexpr (G0 < G1) {
+      parse_group<G0, N, FIXED>(H, waddr, fixed);
+      parse_range<G0 + 1, G1, N, FIXED>(H, waddr, fixed);
+    }
+  } else if constexpr (G0 < G1) {
+    constexpr int GE = G0 + PARSE_BATCH < G1 ? G0 + PARSE_BATCH : G1, NC = 2 * (GE - G0);
+    uint32_t d[NC], st[NC];
+    parse_extract<G0, GE, N>(H, d);
+#pragma unroll
+    for (int c = 0; c < NC; c++) st[c] = accept_step(d[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      lds_st16(waddr, d[c]);
+      waddr += st[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    parse_range<GE, G1, N, FIXED>(H, waddr, fixed);
   }
 }
 
-// A 168-byte block is parsed and drained in two halves.  The staging row of a lane always
-// STARTS at a 64-byte line of its polynomial: after a half-block's parse only whole lines (32
-// coefficients) leave, as aligned 16-byte stores, and the remainder (< 32 coefficients) moves to
-// the front of the row for the next half-block.  Every line of the matrix is written exactly
-// once, whole, and the drain needs no head / tail alignment logic.  (Round 1 drained whatever a
-// half-block produced, ragged ~90-byte pieces at 4-byte alignment: most lines were written twice,
-// 1.41x write traffic, and the kernel was 3 % slower although its rows were smaller.)
-// Row = 31 carried + 56 candidates + 1 spill slot, padded to an odd dword stride: 45 dwords per
-// lane, 46 KB per workgroup, three workgroups per CU (the permutation needs two wavefronts per
-// SIMD for its full rate, tools/microbench/keccak_rate.hip).
-constexpr int MAT_PARTS = 2;
+// A 168-byte block is parsed and drained in four parts.  The staging row of a lane always STARTS
+// at a 64-byte line of its polynomial: after a part's parse a whole line (32 coefficients) leaves,
+// if there is one, as aligned 16-byte stores, and the remainder (< 32 coefficients) moves to the
+// front of the row for the next part.  Every line of the matrix is written exactly once, whole,
+// and the drain needs no head / tail alignment logic.  (Round 1 drained whatever a half-block
+// produced, ragged ~90-byte pieces at 4-byte alignment: most lines were written twice, 1.41x write
+// traffic.)
+// Row = 31 carried + 28 candidates + 1 spill slot = 30 dwords, padded to an odd stride: 31 dwords
+// per lane, 62 KB per 512-lane workgroup, two workgroups per CU -- the residency the phase-locked
+// permutation wants (keccak.h).  A/B on one box, Kyber768 2^19: this layout 1.77-1.79 ms; two parts
+// per block with 32-byte drain units (37-dword rows) 1.81-1.83 ms; the same four parts without the
+// phase lock 1.93 ms; round 2's first layout (256 lanes, two parts, 45-dword rows, three
+// workgroups per CU, no lock) 1.84-1.87 ms.
+constexpr int MAT_PARTS = 4;
 constexpr int MAT_GROUPS = 56 / MAT_PARTS;          // 3-byte groups per part
-constexpr int MAT_STAGE_DW = 45;
+constexpr int MAT_STAGE_DW = 31;
+static_assert(2 * MAT_STAGE_DW >= 31 + 2 * MAT_GROUPS + 1 && MAT_STAGE_DW % 2 == 1, "staging row");
+static_assert(31 + 2 * MAT_GROUPS < 64, "at most one whole line per part");
+static_assert(2 * SPONGE_WG * MAT_STAGE_DW * 4 + 64 <= 160 * 1024, "two workgroups per CU");
 
 // Tail queue: dword 0 = number of records pushed (may exceed the capacity),
 // records of 64 dwords from dword 64: sponge state (50), entry index, count.
@@ -405,12 +442,11 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
 // ABLATE != 0 only in tools/microbench (1: no drain; 2: no parse either; 3: no drain, staging
 // stores at cursor-independent, conflict-free addresses; 4: no drain, no staging stores)
 template <class P, int ABLATE = 0>
-__global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
-                                                          int transposed, int16_t* __restrict__ mat,
-                                                          uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  __shared__ uint32_t stage[4 * 64 * MAT_STAGE_DW + 8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long job = (long)blockIdx.x * 256 + wave * 64 + lane;
+__global__ void __launch_bounds__(SPONGE_WG, 2) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                                   int transposed, int16_t* __restrict__ mat,
+                                                                   uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+  __shared__ uint32_t stage[SPONGE_WG * MAT_STAGE_DW + 8];
+  const long job = (long)blockIdx.x * SPONGE_WG + threadIdx.x;
   const bool valid = job < njobs;
   const long jc = valid ? job : (long)njobs - 1;
   const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
@@ -425,7 +461,7 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
   A[4].lo = x | y << 8 | 0x1F0000u;
   A[20].hi = 0x80000000u;
 
-  uint32_t* row = stage + (wave * 64 + lane) * MAT_STAGE_DW;
+  uint32_t* row = stage + threadIdx.x * MAT_STAGE_DW;
   const uint32_t row_addr = lds_addr(row);
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat) + job * 128;
   int ctr = valid ? 0 : 256;  // coefficients already in memory: a multiple of 32 until the entry is parked
@@ -450,22 +486,22 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
         for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
         waddr += 2 * (91 / MAT_PARTS);
       }
-      const int cnt = pend + (int)((waddr - w0) >> 1);                 // <= 31 + 56
-      const bool live = ctr < 256;
-      const int nl = !live ? 0 : (ctr + cnt >= 256 ? (256 - ctr) >> 5 : cnt >> 5);  // whole lines that leave now: 0..2 (last round: up to 8 - ctr/32)
-      uint4* dst = reinterpret_cast<uint4*>(out32 + (ctr >> 1));
+      const int cnt = pend + (int)((waddr - w0) >> 1);          // <= 31 + 28
+      const bool line = ctr < 256 && cnt >= 32;                 // one whole line leaves now
       if constexpr (ABLATE == 0) {
+        if (line) {
+          uint4* dst = reinterpret_cast<uint4*>(out32 + (ctr >> 1));
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (q < 4 * nl) dst[q] = make_uint4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+          for (int q = 0; q < 4; q++) dst[q] = make_uint4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+        }
       }
-      ctr += 32 * nl;
-      pend = (live && ctr < 256) ? cnt - 32 * nl : 0;
-      if (nl > 0 && pend > 0) {  // the remainder moves to the front (source and destination never overlap)
-        const uint32_t* src = row + 16 * nl;
+      if (line) ctr += 32;
+      const int left = line ? cnt - 32 : cnt;
+      pend = ctr < 256 ? left : 0;
+      if (line && pend > 0) {  // the remainder (<= 27 coefficients) moves to the front
 #pragma unroll
-        for (int d = 0; d < 16; d += 2) {
-          const uint32_t a = src[d], b = src[d + 1];
+        for (int d = 0; d < 14; d += 2) {
+          const uint32_t a = row[16 + d], b = row[17 + d];
           row[d] = a;
           row[d + 1] = b;
         }
@@ -473,6 +509,8 @@ __global__ void __launch_bounds__(256) k_sample_matrix(int njobs, const uint8_t*
     };
     part(std::integral_constant<int, 0>{});
     part(std::integral_constant<int, MAT_GROUPS>{});
+    part(std::integral_constant<int, 2 * MAT_GROUPS>{});
+    part(std::integral_constant<int, 3 * MAT_GROUPS>{});
     if (++blk == MAT_MAIN_BLOCKS && tailq != nullptr && ctr < 256) {
       const uint32_t slot = atomicAdd(tailq, 1u);
       if (slot < tail_cap) {

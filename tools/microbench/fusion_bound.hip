@@ -32,7 +32,7 @@ int main() {
     for (int v = 0; v < 4; v++) {
       const size_t pad = (v & 1) ? ((v < 2) ? 120 * 1024 : 130 * 1024) : 0;  // forces one workgroup per CU
       CK(hipEventRecord(a));
-      if (v < 2) k_s<<<(jobs + 255) / 256, 256, pad>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
+      if (v < 2) k_s<<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG, pad>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
       else k_e<<<(n + 7) / 8, 256, pad>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&t[v], a, b));

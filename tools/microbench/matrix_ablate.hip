@@ -2,23 +2,26 @@
 // product kernel (ABLATE=0) and ablations (1: no drain; 2: no parse, no drain;
 // 3: no drain, staging stores at cursor-independent, bank-conflict-free addresses;
 // 4: no drain, parse arithmetic without any staging store) interleaved in one
-// process on the same seeds.  No tail queue is passed here, so every variant
-// except 2 also runs the 4th SHAKE block for the 41 % of wavefronts that hold a
-// short entry (the product hands those entries to k_sample_matrix_tail).
+// process on the same seeds, at the product's batch (2^19 x 9 entries) and with its tail queue, so
+// that entries still short after three blocks are parked as in the product.
 #include "../../kyber_amd/csrc/kem_kernels.h"
 #include <cstdio>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 using P = ky::Par<3>;
+uint32_t* g_tailq; uint32_t g_cap;
 template <int AB> float run(int n, const uint8_t* seeds, int16_t* mat, hipEvent_t a, hipEvent_t b) {
   int jobs = n * 9;
+  hipMemsetAsync(g_tailq, 0, 4);
   hipEventRecord(a);
-  ky::k_sample_matrix<P, AB><<<(jobs + 255) / 256, 256>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
+  ky::k_sample_matrix<P, AB><<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG>>>(jobs, seeds, 32, 1, mat, g_tailq, g_cap);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms;
 }
 int main() {
-  const int n = 131072;
+  const int n = 524288;
+  g_cap = (uint32_t)ky::tailq_capacity((size_t)n * 9);
+  CK(hipMalloc(&g_tailq, ky::tailq_bytes((size_t)n * 9)));
   uint8_t* seeds; int16_t* mat;
   CK(hipMalloc(&seeds, n * 32)); CK(hipMalloc(&mat, (size_t)n * 9 * 512));
   CK(hipMemset(seeds, 0x3c, n * 32));
