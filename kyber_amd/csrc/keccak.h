@@ -84,18 +84,24 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 // wavefront that runs more permutations than its neighbours pairs its barriers with whoever is left.
 // It is written as asm so that the compiler does not drain the memory counters in front of it.
 constexpr int SPONGE_WG = 512;
-#if defined(KY_KECCAK_PHASED)   // tools/microbench only: 0 = compiler's schedule, 1 = phases without barrier, 2 = product, 3/4 = barrier per round / two rounds
+#if defined(KY_KECCAK_PHASED)   // tools/microbench only: 0 = compiler's schedule, 1 = phases without barrier, 2 = product (barrier at all five phase boundaries), 3/4 = barrier per round / two rounds, 5/6 = fewer barriers per round
 #define KY_LOCK_MODE KY_KECCAK_PHASED
 #else
 #define KY_LOCK_MODE 2
 #endif
 #define KY_SYNC() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// KY_PHASE(n): boundary n of the round (1 after the parities, 2 after their rotates, 3 after theta,
+// 4 after rho, 5 after chi)
 #if KY_LOCK_MODE == 2
-#define KY_PHASE() KY_SYNC()
+#define KY_PHASE(n) KY_SYNC()
 #elif KY_LOCK_MODE == 0
-#define KY_PHASE()
+#define KY_PHASE(n)
+#elif KY_LOCK_MODE == 5   // no barrier between chi and the next round's parities (same class)
+#define KY_PHASE(n) do { if ((n) != 5) KY_SYNC(); else __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif KY_LOCK_MODE == 6   // barriers around the 48 rho rotates only
+#define KY_PHASE(n) do { if ((n) == 3 || (n) == 4) KY_SYNC(); else __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
-#define KY_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define KY_PHASE(n) __builtin_amdgcn_sched_barrier(0)
 #endif
 __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25], uint64_t rc) {
   u64p C[5], R[5], T[25], B[25];
@@ -104,22 +110,22 @@ __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25],
 #endif
 #pragma unroll
   for (int x = 0; x < 5; x++) C[x] = xor3(xor3(A[x], A[x + 5], A[x + 10]), A[x + 15], A[x + 20]);
-  KY_PHASE();
+  KY_PHASE(1);
 #pragma unroll
   for (int x = 0; x < 5; x++) R[x] = rol<1>(C[x]);
-  KY_PHASE();
+  KY_PHASE(2);
   // theta-apply, then rho/pi: B[y, 2x+3y] = rol(A[x,y] ^ C[x-1] ^ rol1(C[x+1]), rho(x,y))
 #pragma unroll
   for (int y = 0; y < 5; y++)
 #pragma unroll
     for (int x = 0; x < 5; x++) T[x + 5 * y] = xor3(A[x + 5 * y], C[(x + 4) % 5], R[(x + 1) % 5]);
-  KY_PHASE();
+  KY_PHASE(3);
 #define KY_RPI(x, y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol<keccak_rho(x, y)>(T[x + 5 * y]);
 #define KY_RPI_ROW(y) KY_RPI(0, y) KY_RPI(1, y) KY_RPI(2, y) KY_RPI(3, y) KY_RPI(4, y)
   KY_RPI_ROW(0) KY_RPI_ROW(1) KY_RPI_ROW(2) KY_RPI_ROW(3) KY_RPI_ROW(4)
 #undef KY_RPI_ROW
 #undef KY_RPI
-  KY_PHASE();
+  KY_PHASE(4);
 #pragma unroll
   for (int y = 0; y < 5; y++)
 #pragma unroll
@@ -127,7 +133,7 @@ __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25],
       E[x + 5 * y] = chi(B[x + 5 * y], B[(x + 1) % 5 + 5 * y], B[(x + 2) % 5 + 5 * y]);
   E[0].lo ^= (uint32_t)rc;
   E[0].hi ^= (uint32_t)(rc >> 32);
-  KY_PHASE();
+  KY_PHASE(5);
 }
 
 __device__ __forceinline__ void keccak_f1600(u64p (&A)[25]) {
