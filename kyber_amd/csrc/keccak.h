@@ -84,48 +84,57 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 // wavefront that runs more permutations than its neighbours pairs its barriers with whoever is left.
 // It is written as asm so that the compiler does not drain the memory counters in front of it.
 constexpr int SPONGE_WG = 512;
-#if defined(KY_KECCAK_PHASED)   // tools/microbench only: 0 = compiler's schedule, 1 = phases without barrier, 2 = product (barrier at all five phase boundaries), 3/4 = barrier per round / two rounds, 5/6 = fewer barriers per round
-#define KY_LOCK_MODE KY_KECCAK_PHASED
+// Below SPONGE_WG_MIN_ITEMS sponges a launch cannot fill the chip with 512-lane workgroups (one
+// per CU = 131072 lanes): it then runs one wavefront per workgroup, which spreads the wavefronts
+// over all SIMDs (the barrier of a one-wavefront workgroup is a no-op).  Kernels index with
+// blockDim.x, so the host picks the size per launch.
+constexpr int SPONGE_WG_SMALL = 64;
+constexpr size_t SPONGE_WG_MIN_ITEMS = 131072;
+__host__ __device__ constexpr unsigned sponge_wg(size_t items) { return items >= SPONGE_WG_MIN_ITEMS ? SPONGE_WG : SPONGE_WG_SMALL; }
+// Lock modes: 0 = the compiler's own schedule, 2 = the phase lock (product).  tools/microbench also
+// builds 1 (phases, no barrier), 3 / 4 (a barrier per round / per two rounds) and 5 / 6 (four / two
+// barriers per round) through -DKY_KECCAK_PHASED=<mode>.  Small launches (one-wavefront
+// workgroups) keep mode 2: the matrix sampler instantiated with mode 0 for them made 4096-instance
+// calls 10 % slower, not faster.
+#if defined(KY_KECCAK_PHASED)
+constexpr int KY_LOCK_MODE = KY_KECCAK_PHASED;
 #else
-#define KY_LOCK_MODE 2
+constexpr int KY_LOCK_MODE = 2;
 #endif
-#define KY_SYNC() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier"); __builtin_amdgcn_sched_barrier(0); } while (0)
-// KY_PHASE(n): boundary n of the round (1 after the parities, 2 after their rotates, 3 after theta,
-// 4 after rho, 5 after chi)
-#if KY_LOCK_MODE == 2
-#define KY_PHASE(n) KY_SYNC()
-#elif KY_LOCK_MODE == 0
-#define KY_PHASE(n)
-#elif KY_LOCK_MODE == 5   // no barrier between chi and the next round's parities (same class)
-#define KY_PHASE(n) do { if ((n) != 5) KY_SYNC(); else __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif KY_LOCK_MODE == 6   // barriers around the 48 rho rotates only
-#define KY_PHASE(n) do { if ((n) == 3 || (n) == 4) KY_SYNC(); else __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define KY_PHASE(n) __builtin_amdgcn_sched_barrier(0)
-#endif
+__device__ __forceinline__ void ky_sync() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// boundary n of the round: 1 after the parities, 2 after their rotates, 3 after theta, 4 after rho, 5 after chi
+template <int MODE, int N>
+__device__ __forceinline__ void ky_phase() {
+  if constexpr (MODE == 0) return;
+  else if constexpr (MODE == 2 || (MODE == 5 && N != 5) || (MODE == 6 && (N == 3 || N == 4))) ky_sync();
+  else __builtin_amdgcn_sched_barrier(0);
+}
+template <int MODE>
 __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25], uint64_t rc) {
   u64p C[5], R[5], T[25], B[25];
-#if KY_LOCK_MODE == 3
-  KY_SYNC();
-#endif
+  if constexpr (MODE == 3) ky_sync();
 #pragma unroll
   for (int x = 0; x < 5; x++) C[x] = xor3(xor3(A[x], A[x + 5], A[x + 10]), A[x + 15], A[x + 20]);
-  KY_PHASE(1);
+  ky_phase<MODE, 1>();
 #pragma unroll
   for (int x = 0; x < 5; x++) R[x] = rol<1>(C[x]);
-  KY_PHASE(2);
+  ky_phase<MODE, 2>();
   // theta-apply, then rho/pi: B[y, 2x+3y] = rol(A[x,y] ^ C[x-1] ^ rol1(C[x+1]), rho(x,y))
 #pragma unroll
   for (int y = 0; y < 5; y++)
 #pragma unroll
     for (int x = 0; x < 5; x++) T[x + 5 * y] = xor3(A[x + 5 * y], C[(x + 4) % 5], R[(x + 1) % 5]);
-  KY_PHASE(3);
+  ky_phase<MODE, 3>();
 #define KY_RPI(x, y) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol<keccak_rho(x, y)>(T[x + 5 * y]);
 #define KY_RPI_ROW(y) KY_RPI(0, y) KY_RPI(1, y) KY_RPI(2, y) KY_RPI(3, y) KY_RPI(4, y)
   KY_RPI_ROW(0) KY_RPI_ROW(1) KY_RPI_ROW(2) KY_RPI_ROW(3) KY_RPI_ROW(4)
 #undef KY_RPI_ROW
 #undef KY_RPI
-  KY_PHASE(4);
+  ky_phase<MODE, 4>();
 #pragma unroll
   for (int y = 0; y < 5; y++)
 #pragma unroll
@@ -133,18 +142,19 @@ __device__ __forceinline__ void keccak_round(const u64p (&A)[25], u64p (&E)[25],
       E[x + 5 * y] = chi(B[x + 5 * y], B[(x + 1) % 5 + 5 * y], B[(x + 2) % 5 + 5 * y]);
   E[0].lo ^= (uint32_t)rc;
   E[0].hi ^= (uint32_t)(rc >> 32);
-  KY_PHASE(5);
+  ky_phase<MODE, 5>();
 }
 
+// LOCK = false: the compiler's schedule (microbenchmarks)
+template <bool LOCK = true>
 __device__ __forceinline__ void keccak_f1600(u64p (&A)[25]) {
+  constexpr int MODE = LOCK ? KY_LOCK_MODE : 0;
   u64p E[25];
 #pragma unroll 1
   for (int r = 0; r < 24; r += 2) {
-#if KY_LOCK_MODE == 4
-    KY_SYNC();
-#endif
-    keccak_round(A, E, KECCAK_RC[r]);
-    keccak_round(E, A, KECCAK_RC[r + 1]);
+    if constexpr (MODE == 4) ky_sync();
+    keccak_round<MODE>(A, E, KECCAK_RC[r]);
+    keccak_round<MODE>(E, A, KECCAK_RC[r + 1]);
   }
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void st32B(uint8_t* p, const u64p& a, const u64p& b, 
 // ------------------------------------------------------------------ FO hashes
 // keypair, before: (rho, sigma) = G(d).                        ref/indcpa.c:215-216
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
   ld32B(coins + (size_t)i * 64, d);
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_pre(int n, const uint8_t* _
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  uint8_t* __restrict__ sk) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p A[25], z[4];
   keccak_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB);
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64) k_hash_pk(const uint8_t* __restrict__ pk, 
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   ld32B(coins + (size_t)i * 32, m);
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_enc_pre(int n, const uint8_t* 
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
                                                  uint8_t* __restrict__ small) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   uint8_t* s = small + (size_t)i * SMALL;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_dec_mid(int n, const uint8_t* 
 template <class P, bool DEC>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                               const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p A[25], kb[4], h[4];
   keccak_absorb_words<136, 0x06, P::CTB>(A, ct + (size_t)i * P::CTB);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_post(int n, const uint8_t* __r
 
 // keypair, before: (rho, sigma) = G(d || k)
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
   ld32B(coins + (size_t)i * 64, d);
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_kp_pre(int n, int k, const 
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                     uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p A[25], m[4], h[4];
   ld32B(coins + (size_t)i * 32, m);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_enc_pre(int n, const uint8_
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                                      const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr int RW = 17, TOTW = 4 + P::CTB / 8, NFULL = TOTW / RW, TAILW = TOTW % RW;
   const uint8_t* c = ct + (size_t)i * P::CTB;
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_post_dec(int n, const uint8
 //   dk: the same for the embedded ek, and H(ek) equals the stored hash ("hash check")
 template <class P, bool DK>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* ek = key + (size_t)i * (DK ? P::SKB : P::PKB) + (DK ? P::PVB : 0);
   uint32_t bad = 0;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_check(int n, const uint8_t*
 template <class P>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
                                              int seed_off, uint8_t* __restrict__ prf) {
-  long gid = (long)blockIdx.x * SPONGE_WG + threadIdx.x;
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * njobs_per_inst) return;
   int nonce = (int)(gid / n), inst = (int)(gid % n);
   u64p A[25], key[4];
@@ -441,12 +441,15 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
 
 // ABLATE != 0 only in tools/microbench (1: no drain; 2: no parse either; 3: no drain, staging
 // stores at cursor-independent, conflict-free addresses; 4: no drain, no staging stores)
-template <class P, int ABLATE = 0>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+// WG = lanes per workgroup: SPONGE_WG, or SPONGE_WG_SMALL for launches that cannot fill the chip
+// (keccak.h).  The staging tile is static LDS: as dynamic LDS of the same size the kernel ran at one
+// workgroup per CU (2.35 instead of 1.79 ms).
+template <class P, int WG = SPONGE_WG, int ABLATE = 0>
+__global__ void __launch_bounds__(WG, 2 * SPONGE_WG / WG) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                                    int transposed, int16_t* __restrict__ mat,
                                                                    uint32_t* __restrict__ tailq, uint32_t tail_cap) {
   __shared__ uint32_t stage[SPONGE_WG * MAT_STAGE_DW + 8];
-  const long job = (long)blockIdx.x * SPONGE_WG + threadIdx.x;
+  const long job = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = job < njobs;
   const long jc = valid ? job : (long)njobs - 1;
   const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict
 template <int NP, bool N90>
 __global__ void __launch_bounds__(SPONGE_WG, 2) k_kdf_parts(int n, const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
                                                    const uint8_t* __restrict__ p2, uint8_t* __restrict__ out) {
-  int i = blockIdx.x * SPONGE_WG + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p a[4], b[4], c[4], r[4];
   ld32B(p0 + (size_t)i * 32, a);

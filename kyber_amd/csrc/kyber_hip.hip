@@ -208,8 +208,12 @@ template <class P>
 int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, uint32_t* tailq,
                   uint32_t tail_cap, hipStream_t st) {
   HIP_TRY(hipMemsetAsync(tailq, 0, sizeof(uint32_t), st));
-  RUN("k_sample_matrix", st,
-      k_sample_matrix<P><<<blocks((size_t)entries, SPONGE_WG), SPONGE_WG, 0, st>>>(entries, rho, rho_stride, transposed, mat, tailq, tail_cap));
+  if (sponge_wg(entries) == SPONGE_WG)
+    RUN("k_sample_matrix", st,
+        (k_sample_matrix<P, SPONGE_WG><<<blocks((size_t)entries, SPONGE_WG), SPONGE_WG, 0, st>>>(entries, rho, rho_stride, transposed, mat, tailq, tail_cap)));
+  else
+    RUN("k_sample_matrix", st,
+        (k_sample_matrix<P, SPONGE_WG_SMALL><<<blocks((size_t)entries, SPONGE_WG_SMALL), SPONGE_WG_SMALL, 0, st>>>(entries, rho, rho_stride, transposed, mat, tailq, tail_cap)));
   if (tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(tail_cap, 64), 64, 0, st>>>(tailq, tail_cap, mat));
   return 0;
 }
@@ -241,18 +245,18 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     const uint8_t* c = coins + o * 64;
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
     if constexpr (N90) RUN("k90_kp_pre", st, k90_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
-    else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, L.small));
+    else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small));
     if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     } else {
-      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     }
     RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
     if constexpr (N90) {
       RUN("k90_kp_post", st, k90_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
     } else {
-      RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, p, s));
+      RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, p, s));
     }
   }
   return 0;
@@ -287,20 +291,20 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     if constexpr (N90) {
       RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     } else {
-      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
+      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     }
     if (!shared)
       if (int rc = expand_matrix<P, N90>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
-      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
     RUN("k_enc_arith", st, launch_enc_arith<P, false>(st, m, p, pk_stride, L.small, mat, mat_stride, L.prf, c));
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, false><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
+      RUN("k_post", st, k_post<P, false><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     }
   }
   return 0;
@@ -324,14 +328,14 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
-      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, s, sk_stride, L.small));
+      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, sk_stride, L.small));
     }
     if (!shared)
       if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
-      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
     // re-encrypt with pk = sk + PVB and compare against ct (ct is only read)
     RUN("k_enc_arith_cmp", st,
@@ -339,7 +343,7 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, true><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
+      RUN("k_post", st, k_post<P, true><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     }
   }
   return 0;
@@ -371,11 +375,11 @@ int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hip
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
     uint8_t *p = ek + o * P::PKB, *s = dk + o * P::SKB;
-    RUN("k_ml_kp_pre", st, k_ml_kp_pre<<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, P::K, c, L.small));
+    RUN("k_ml_kp_pre", st, k_ml_kp_pre<<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, P::K, c, L.small));
     if (int rc = expand_matrix<P, false>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
-    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, p, s));  // dk tail = H(ek) || z, as in round 3
+    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, p, s));  // dk tail = H(ek) || z, as in round 3
   }
   return 0;
 }
@@ -393,9 +397,9 @@ int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = ek + o * P::PKB;
     uint8_t* c = ct + o * P::CTB;
-    RUN("k_ml_enc_pre", st, k_ml_enc_pre<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, coins + o * 32, p, L.small, ss + o * 32));
+    RUN("k_ml_enc_pre", st, k_ml_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, L.small, ss + o * 32));
     if (int rc = expand_matrix<P, false>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     RUN("k_enc_arith", st, launch_enc_arith<P, false>(st, m, p, P::PKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, c));
   }
   return 0;
@@ -415,20 +419,20 @@ int ml_dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, hipS
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = dk + o * P::SKB;
     RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, P::SKB, L.small));
-    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, s, P::SKB, L.small));
+    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, P::SKB, L.small));
     if (int rc = expand_matrix<P, false>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), SPONGE_WG), SPONGE_WG, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     RUN("k_enc_arith_cmp", st,
         launch_enc_arith<P, true>(st, m, s + P::PVB, P::SKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, const_cast<uint8_t*>(c)));
-    RUN("k_ml_post_dec", st, k_ml_post_dec<P><<<blocks(m, SPONGE_WG), SPONGE_WG, 0, st>>>(m, c, L.small, s, P::SKB, ss + o * 32));
+    RUN("k_ml_post_dec", st, k_ml_post_dec<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, s, P::SKB, ss + o * 32));
   }
   return 0;
 }
 
 template <class P>
 int ml_check_dev(size_t n, const uint8_t* key, int is_dk, uint32_t* flags, hipStream_t st) {
-  if (is_dk) RUN("k_ml_check", st, k_ml_check<P, true><<<blocks(n, SPONGE_WG), SPONGE_WG, 0, st>>>((int)n, key, flags));
-  else RUN("k_ml_check", st, k_ml_check<P, false><<<blocks(n, SPONGE_WG), SPONGE_WG, 0, st>>>((int)n, key, flags));
+  if (is_dk) RUN("k_ml_check", st, k_ml_check<P, true><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, key, flags));
+  else RUN("k_ml_check", st, k_ml_check<P, false><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, key, flags));
   return 0;
 }
 
@@ -477,8 +481,13 @@ int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed,
     RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
   } else {
     // no workspace here: a null queue keeps every entry in the main kernel until it is complete
-    RUN("k_sample_matrix", st,
-        k_sample_matrix<P><<<blocks(n * P::NMAT, SPONGE_WG), SPONGE_WG, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat, nullptr, 0u));
+    const size_t entries = n * P::NMAT;
+    if (sponge_wg(entries) == SPONGE_WG)
+      RUN("k_sample_matrix", st,
+          (k_sample_matrix<P, SPONGE_WG><<<blocks(entries, SPONGE_WG), SPONGE_WG, 0, st>>>((int)entries, seeds, 32, transposed, mat, nullptr, 0u)));
+    else
+      RUN("k_sample_matrix", st,
+          (k_sample_matrix<P, SPONGE_WG_SMALL><<<blocks(entries, SPONGE_WG_SMALL), SPONGE_WG_SMALL, 0, st>>>((int)entries, seeds, 32, transposed, mat, nullptr, 0u)));
   }
   return 0;
 }
@@ -512,7 +521,7 @@ inline int copy_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spi
 
 template <int NP, bool N90>
 int kdf_parts(size_t n, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, uint8_t* out, hipStream_t st) {
-  RUN("k_kdf_parts", st, k_kdf_parts<NP, N90><<<blocks(n, SPONGE_WG), SPONGE_WG, 0, st>>>((int)n, p0, p1, p2, out));
+  RUN("k_kdf_parts", st, k_kdf_parts<NP, N90><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, p0, p1, p2, out));
   return 0;
 }
 

@@ -24,7 +24,7 @@ int main() {
   { std::vector<uint32_t> h(n * 8); for (int i = 0; i < n * 8; i++) h[i] = i * 2654435761u; CK(hipMemcpy(seeds, h.data(), n * 32, hipMemcpyHostToDevice)); }
   CK(hipMemset(pk, 0x11, (size_t)n * P::PKB)); CK(hipMemset(small, 0x22, (size_t)n * 128)); CK(hipMemset(prf, 0x33, (size_t)n * 7 * 128));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  auto k_s = ky::k_sample_matrix<P, 0>;
+  auto k_s = ky::k_sample_matrix<P, ky::SPONGE_WG, 0>;
   auto k_e = ky::k_enc_arith<P, false>;
   const int jobs = n * 9;
   for (int r = 0; r < 3; r++) {

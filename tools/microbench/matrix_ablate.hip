@@ -13,7 +13,7 @@ template <int AB> float run(int n, const uint8_t* seeds, int16_t* mat, hipEvent_
   int jobs = n * 9;
   hipMemsetAsync(g_tailq, 0, 4);
   hipEventRecord(a);
-  ky::k_sample_matrix<P, AB><<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG>>>(jobs, seeds, 32, 1, mat, g_tailq, g_cap);
+  ky::k_sample_matrix<P, ky::SPONGE_WG, AB><<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG>>>(jobs, seeds, 32, 1, mat, g_tailq, g_cap);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms;
