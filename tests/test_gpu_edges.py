@@ -134,3 +134,32 @@ def test_one_million_instances_other_sets(oracle, k, n90):
     assert np.array_equal(ssr[j].cpu().numpy(), oracle.dec(k, ct[j].cpu().numpy(), sk[j].cpu().numpy(), n90))
     del pk, sk, ct, ssa, ssb, ssr, kc, ec
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_batch_sizes_around_the_workgroup_switch(oracle, k):
+    """The sponge kernels run one-wavefront workgroups below 131072 sponges per launch and
+    512-lane phase-locked workgroups from there on (keccak.h sponge_wg): batch sizes that put
+    the matrix sampler (K*K sponges per instance), the PRF (2K+1) and the hashes (1) on either
+    side of the switch, last workgroup ragged.  Strided sample against the oracle, every
+    instance round-trips."""
+    import torch
+    kem = kyber_amd.KyberHip(k, 0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77 + k)
+    switch = 131072
+    sizes = sorted({switch // (k * k), switch // (k * k) + 1, switch // (2 * k + 1) + 1, switch - 1, switch + 1})
+    for n in sizes:
+        kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+        ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        pk, sk = kem.keypair_dev(kc)
+        ct, ssb = kem.enc_dev(pk, ec)
+        ssa = kem.dec_dev(ct, sk)
+        assert torch.equal(ssa, ssb), n
+        idx = torch.cat([torch.arange(0, n, 997, device="cuda"), torch.arange(n - 70, n, device="cuda")])
+        opk, osk = oracle.keypair(k, kc[idx].cpu().numpy(), 0)
+        oct_, oss = oracle.enc(k, opk, ec[idx].cpu().numpy(), 0)
+        assert np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk), n
+        assert np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssb[idx].cpu().numpy(), oss), n
+        del pk, sk, ct, ssa, ssb, kc, ec
+    torch.cuda.empty_cache()
