@@ -42,5 +42,33 @@ int main() {
     printf("round %d (n = %d): k_sample_matrix %.3f ms, at one workgroup per CU %.3f ms (x%.2f) | k_enc_arith %.3f ms, at one workgroup per CU %.3f ms (x%.2f)\n",
            r, n, t[0], t[1], t[1] / t[0], t[2], t[3], t[3] / t[2]);
   }
+  // Do the two kinds of kernel overlap to advantage?  The sampler on one stream and the encryption
+  // arithmetic (twice: about the same duration) on another, against the same three launches in sequence.
+  {
+    hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s), hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_e), hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+    for (int r = 0; r < 4; r++) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, s1));
+      k_s<<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG, 0, s1>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
+      k_e<<<(n + 7) / 8, 256, 0, s1>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
+      k_e<<<(n + 7) / 8, 256, 0, s1>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
+      CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1));
+      float seq; CK(hipEventElapsedTime(&seq, e0, e1));
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, s1));
+      CK(hipStreamWaitEvent(s2, e0, 0));
+      k_s<<<(jobs + ky::SPONGE_WG - 1) / ky::SPONGE_WG, ky::SPONGE_WG, 0, s1>>>(jobs, seeds, 32, 1, mat, nullptr, 0u);
+      k_e<<<(n + 7) / 8, 256, 0, s2>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
+      k_e<<<(n + 7) / 8, 256, 0, s2>>>(n, pk, P::PKB, small, mat, (size_t)9 * 256, prf, ct);
+      CK(hipEventRecord(e2, s2));
+      CK(hipStreamWaitEvent(s1, e2, 0));
+      CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1));
+      float con; CK(hipEventElapsedTime(&con, e0, e1));
+      printf("round %d: sampler + 2 x k_enc_arith in sequence %.3f ms, on two streams %.3f ms (x%.2f)\n", r, seq, con, con / seq);
+    }
+  }
   return 0;
 }
