@@ -83,6 +83,9 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 // The barrier only aligns issue: no data crosses it, waves that have ended do not count, and a
 // wavefront that runs more permutations than its neighbours pairs its barriers with whoever is left.
 // It is written as asm so that the compiler does not drain the memory counters in front of it.
+// For the same reason a kernel that calls the permutation must not ALSO use __syncthreads() for data
+// (none does: sponge kernels share nothing between lanes): a wavefront inside a permutation would
+// answer the data barrier of one that is not.
 constexpr int SPONGE_WG = 512;
 // Below SPONGE_WG_MIN_ITEMS sponges a launch cannot fill the chip with 512-lane workgroups (one
 // per CU = 131072 lanes): it then runs one wavefront per workgroup, which spreads the wavefronts
