@@ -87,6 +87,8 @@ __host__ __device__ constexpr int keccak_rho(int x, int y) {
 // (none does: sponge kernels share nothing between lanes): a wavefront inside a permutation would
 // answer the data barrier of one that is not.
 constexpr int SPONGE_WG = 512;
+// (hipcc's second __launch_bounds__ argument is wavefronts per SIMD, not workgroups per CU: the sponge
+// kernels ask for 4 = two 512-lane workgroups per CU, i.e. at most 128 VGPRs)
 // Below SPONGE_WG_MIN_ITEMS sponges a launch cannot fill the chip with 512-lane workgroups (one
 // per CU = 131072 lanes): it then runs one wavefront per workgroup, which spreads the wavefronts
 // over all SIMDs (the barrier of a one-wavefront workgroup is a no-op).  Kernels index with
@@ -97,8 +99,8 @@ __host__ __device__ constexpr unsigned sponge_wg(size_t items) { return items >=
 // Lock modes: 0 = the compiler's own schedule, 2 = the phase lock (product).  tools/microbench also
 // builds 1 (phases, no barrier), 3 / 4 (a barrier per round / per two rounds) and 5 / 6 (four / two
 // barriers per round) through -DKY_KECCAK_PHASED=<mode>.  Small launches (one-wavefront
-// workgroups) keep mode 2: the matrix sampler instantiated with mode 0 for them made 4096-instance
-// calls 10 % slower, not faster.
+// workgroups) keep mode 2: the matrix sampler instantiated with mode 0 for them changed nothing
+// measurable at 256 and 4096 instances per call.
 #if defined(KY_KECCAK_PHASED)
 constexpr int KY_LOCK_MODE = KY_KECCAK_PHASED;
 #else

@@ -62,7 +62,7 @@ __device__ __forceinline__ void st32B(uint8_t* p, const u64p& a, const u64p& b, 
 
 // ------------------------------------------------------------------ FO hashes
 // keypair, before: (rho, sigma) = G(d).                        ref/indcpa.c:215-216
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_pre(int n, const uint8_t* _
 
 // keypair, after: sk tail = H(pk) || z.                          ref/kem.c:30-32
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_kp_post(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  uint8_t* __restrict__ sk) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) k_hash_pk(const uint8_t* __restrict__ pk, 
 // encaps, before: m = H(m0); (Kbar, r) = G(m || H(pk)).         ref/kem.c:59-65
 // hpk != null: every instance uses that one precomputed H(pk) (shared key).
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                  const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_enc_pre(int n, const uint8_t* 
 
 // decaps, middle: (Kbar', r') = G(m' || H(pk) from sk).          ref/kem.c:109-111
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride,
                                                  uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_dec_mid(int n, const uint8_t* 
 
 // encaps/decaps, after: ss = KDF(Kbar-or-z || H(ct)).            ref/kem.c:71-73, :116-125
 template <class P, bool DEC>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_post(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                               const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_post(int n, const uint8_t* __r
 // (Decaps_internal: implicit rejection key J(z || c) = SHAKE256(z || c, 32)).
 
 // keypair, before: (rho, sigma) = G(d || k)
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_kp_pre(int n, int k, const 
 
 // encaps: (K, r) = G(m || H(ek)); the shared secret is K itself
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
                                                     uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_enc_pre(int n, const uint8_
 
 // decaps, after: ss = (c == c') ? K' : J(z || c), selected without a branch
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_post_dec(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small,
                                                      const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_post_dec(int n, const uint8
 //   ek: every 12-bit coefficient of the encoded t^ is below q ("modulus check")
 //   dk: the same for the embedded ek, and H(ek) equals the stored hash ("hash check")
 template <class P, bool DK>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_check(int n, const uint8_t* __restrict__ key, uint32_t* __restrict__ flags) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* ek = key + (size_t)i * (DK ? P::SKB : P::PKB) + (DK ? P::PVB : 0);
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 2) k_ml_check(int n, const uint8_t*
 // binomial map is applied by the consumer in poly layout.
 // ref/symmetric-shake.c:43-51 + ref/poly.c:208-232 (prf part).
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
                                              int seed_off, uint8_t* __restrict__ prf) {
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * njobs_per_inst) return;
@@ -442,14 +442,13 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
 // ABLATE != 0 only in tools/microbench (1: no drain; 2: no parse either; 3: no drain, staging
 // stores at cursor-independent, conflict-free addresses; 4: no drain, no staging stores)
 // WG = lanes per workgroup: SPONGE_WG, or SPONGE_WG_SMALL for launches that cannot fill the chip
-// (keccak.h).  The staging tile is static LDS: as dynamic LDS of the same size the kernel ran at one
-// workgroup per CU (2.35 instead of 1.79 ms).
+// (keccak.h); the staging tile is sized by it.
 template <class P, int WG = SPONGE_WG, int ABLATE = 0>
-__global__ void __launch_bounds__(WG, 2 * SPONGE_WG / WG) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+__global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                                    int transposed, int16_t* __restrict__ mat,
                                                                    uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  __shared__ uint32_t stage[SPONGE_WG * MAT_STAGE_DW + 8];
-  const long job = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t stage[WG * MAT_STAGE_DW + 8];  // the last lane's remainder move may read 8 dwords past its row
+  const long job = (long)blockIdx.x * WG + threadIdx.x;
   const bool valid = job < njobs;
   const long jc = valid ? job : (long)njobs - 1;
   const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);

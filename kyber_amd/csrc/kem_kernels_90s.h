@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k90_post(int n, const uint8_t* __restrict
 // arrays: out = kdf(p0 || p1 [|| p2]).  ref/kex.c:17,26,42,52 with
 // ref/symmetric.h:32,56 (SHAKE256 / SHA-256).
 template <int NP, bool N90>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_kdf_parts(int n, const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_kdf_parts(int n, const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
                                                    const uint8_t* __restrict__ p2, uint8_t* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

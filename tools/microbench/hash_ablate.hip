@@ -11,7 +11,7 @@ using namespace ky;
 using P = Par<3>;
 
 template <int MODE>
-__global__ void __launch_bounds__(SPONGE_WG, 2) k_post_var(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_post_var(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
   int i = blockIdx.x * SPONGE_WG + threadIdx.x;
   if (i >= n) return;
   u64p A[25], kb[4], h[4];
