@@ -141,12 +141,16 @@ __device__ __forceinline__ void f_gs(float& a, float& b, float z) {  // Gentlema
 // Values then stay <= 78 + 6 * 1665 = 10068 up to the last layer, whose products
 // are <= 1664 * 10068 = 16.75 M < 2^24, so the reduction after the third layer
 // is left out.
+// KY_ABLATE_NTT_LDS (tools/microbench only): the transposes between the passes are left out, which
+// makes the results wrong and prices what the LDS round trips cost the arithmetic kernels.
+#ifdef KY_ABLATE_NTT_LDS
+#define KY_XPOSE(put, get) do { } while (0)
+#else
+#define KY_XPOSE(put, get) do { KY_WSYNC(); put(p, t, c); KY_WSYNC(); get(p, t, c); } while (0)
+#endif
 template <bool SMALL_IN = false>
 __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float (&c)[8]) {
-  KY_WSYNC();
-  f_put_contig(p, t, c);
-  KY_WSYNC();
-  f_get_stride(p, t, c);
+  KY_XPOSE(f_put_contig, f_get_stride);
 #pragma unroll
   for (int m = 0; m < 4; m++) f_ct(c[m], c[m + 4], ZETAF[1]);
   f_ct(c[0], c[2], ZETAF[2]); f_ct(c[1], c[3], ZETAF[2]);
@@ -157,10 +161,7 @@ __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float
 #pragma unroll
     for (int m = 0; m < 8; m++) c[m] = fred(c[m]);
   }
-  KY_WSYNC();
-  f_put_stride(p, t, c);
-  KY_WSYNC();
-  f_get_middle(p, t, c);
+  KY_XPOSE(f_put_stride, f_get_middle);
   {
     const int hi = t >> 2;
     float z = Z[8 + hi];
@@ -172,10 +173,7 @@ __device__ __forceinline__ void f_ntt_fwd(float* p, const float* Z, int t, float
     f_ct(c[0], c[1], Z[32 + 4 * hi]); f_ct(c[2], c[3], Z[33 + 4 * hi]);
     f_ct(c[4], c[5], Z[34 + 4 * hi]); f_ct(c[6], c[7], Z[35 + 4 * hi]);
   }
-  KY_WSYNC();
-  f_put_middle(p, t, c);
-  KY_WSYNC();
-  f_get_contig(p, t, c);
+  KY_XPOSE(f_put_middle, f_get_contig);
   {
     float z0 = Z[64 + 2 * t], z1 = Z[65 + 2 * t];
     f_ct(c[0], c[2], z0); f_ct(c[1], c[3], z0);
@@ -202,10 +200,7 @@ __device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float
     f_gs(c[0], c[2], z0); f_gs(c[1], c[3], z0);
     f_gs(c[4], c[6], z1); f_gs(c[5], c[7], z1);
   }
-  KY_WSYNC();
-  f_put_contig(p, t, c);
-  KY_WSYNC();
-  f_get_middle(p, t, c);
+  KY_XPOSE(f_put_contig, f_get_middle);
   {
     const int hi = t >> 2;
     f_gs(c[0], c[1], Z[63 - 4 * hi]); f_gs(c[2], c[3], Z[62 - 4 * hi]);
@@ -219,10 +214,7 @@ __device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float
     for (int m = 0; m < 4; m++) f_gs(c[m], c[m + 4], z);
     c[0] = fred(c[0]); c[1] = fred(c[1]); c[2] = fred(c[2]); c[3] = fred(c[3]);
   }
-  KY_WSYNC();
-  f_put_middle(p, t, c);
-  KY_WSYNC();
-  f_get_stride(p, t, c);
+  KY_XPOSE(f_put_middle, f_get_stride);
   f_gs(c[0], c[1], ZETAF[7]); f_gs(c[2], c[3], ZETAF[6]);
   f_gs(c[4], c[5], ZETAF[5]); f_gs(c[6], c[7], ZETAF[4]);
   f_gs(c[0], c[2], ZETAF[3]); f_gs(c[1], c[3], ZETAF[3]);
@@ -234,10 +226,7 @@ __device__ __forceinline__ void f_ntt_inv(float* p, const float* Z, int t, float
 #pragma unroll
     for (int m = 0; m < 8; m++) c[m] = fmm(c[m], KY_NINV_PLAIN);  // |c| <= 3336, * 26
   }
-  KY_WSYNC();
-  f_put_stride(p, t, c);
-  KY_WSYNC();
-  f_get_contig(p, t, c);
+  KY_XPOSE(f_put_stride, f_get_contig);
 }
 
 // ---------------------------------------------------------------- basemul
