@@ -56,3 +56,32 @@ def test_noalloc_rejects_oversize_and_bad_arguments():
                                          ctypes.c_void_p(sk.data_ptr()), None) == -1
     assert L.kyber_batch_dec_dev_noalloc(3, 0, 0, ctypes.c_void_p(ss.data_ptr()), ctypes.c_void_p(ct.data_ptr()),
                                          ctypes.c_void_p(sk.data_ptr()), None) == 0
+
+
+def test_noalloc_can_be_captured_in_a_graph(oracle):
+    """The callers this entry point exists for: under stream capture nothing may allocate.  The
+    first call (outside capture) takes the scratch array's address; a captured call replays
+    with the same bytes as kyber_batch_dec_dev, also after an input changed in place."""
+    kem = kyber_amd.KyberHip(3)
+    n = 1024
+    ct, sk = _instances(kem, n, 4242, oracle)
+    want = kem.dec_dev(ct, sk)
+    out = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    kem.dec_dev_noalloc(ct, sk, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    out.zero_()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            kem.dec_dev_noalloc(ct, sk, out)
+    torch.cuda.synchronize()
+    assert int(out.sum()) == 0            # capture records, it does not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    ct[1, 7] ^= 0x10                      # instance 1 was valid (only every fifth is corrupted): now it is rejected
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, kem.dec_dev(ct, sk)) and not torch.equal(out[1], want[1])
