@@ -190,6 +190,27 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t *r, const int16_t *a, c
  * gen_matrix: mat[i][e][256] int16, e = row*k + col of A (transposed = 0) or
  * A^T (transposed = 1) expanded from seeds[i][32].        ref/indcpa.c:164-192 */
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, const uint8_t *seeds, int transposed, void *stream);
+/* getnoise: r[i][nonce][256] = poly_getnoise(seeds[i], nonce) for nonce = 0..nnonce-1, with eta1 for
+ * nonce < n_eta1 and eta2 above -- the PRF kernel of the KEM pipelines followed by the centred
+ * binomial map.                      ref/poly.c:208-232, ref/symmetric-shake.c:43-51 / symmetric-aes.c:15-20
+ * cbd: r[i] = cbd_eta(buf[i]), buf = 64*eta bytes per polynomial, eta = 2 or 3.        ref/cbd.c:58-107 */
+int kyber_batch_getnoise_dev(int k, int nineties, size_t n, int nnonce, int n_eta1, int16_t *r, const uint8_t *seeds, void *stream);
+int kyber_batch_poly_cbd_dev(int eta, size_t npoly, int16_t *r, const uint8_t *buf, void *stream);
+/* codecs, polynomial by polynomial, through the device functions the KEM kernels use:
+ *   tobytes / frombytes   384 bytes per polynomial                          ref/poly.c:111-145
+ *   compress / decompress 32*d bytes per polynomial, d = 4, 5 (poly_compress, ref/poly.c:18-100),
+ *                         d = 10, 11 (one polynomial of polyvec_compress, ref/polyvec.c:15-115),
+ *                         d = 1 (poly_tomsg / poly_frommsg, ref/poly.c:155-194)
+ * compress and tobytes accept any representative in (-q, q) (|a| <= 5000 for compress). */
+int kyber_batch_poly_tobytes_dev(size_t npoly, uint8_t *r, const int16_t *a, void *stream);
+int kyber_batch_poly_frombytes_dev(size_t npoly, int16_t *r, const uint8_t *a, void *stream);
+int kyber_batch_poly_compress_dev(int d, size_t npoly, uint8_t *r, const int16_t *a, void *stream);
+int kyber_batch_poly_decompress_dev(int d, size_t npoly, int16_t *r, const uint8_t *a, void *stream);
+/* polyvec_basemul_acc on the fp32 engine, as the KEM kernels accumulate a matrix row against the
+ * cached multiplicand: r[i] = centred residue of sum_{j<k} a[i][j] o b[i][j] WITHOUT the 2^-16 of the
+ * reference's Montgomery products (ref/polyvec.c:189-201 gives r * 2^-16 mod q); a[i][j] canonical
+ * in [0, q), b[i][j] centred with |b| <= 1665. */
+int kyber_batch_polyvec_basemul_acc_dev(int k, size_t nvec, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
 
 /* ---- pinned host memory (optional) ----
  * The host-pointer entry points overlap PCIe copies with the kernels; the

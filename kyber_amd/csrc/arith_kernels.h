@@ -532,4 +532,131 @@ __global__ void __launch_bounds__(256) k_poly_mul_fused(long npoly, int16_t* r, 
   }
 }
 
+// ------------------------------------------------------------------ single-function stages
+// The codecs, the noise map and the accumulated base multiplication as kernels of their own, built
+// from the very device functions the KEM kernels above use, so that a parity failure of the KEM
+// can be localised (tests/test_gpu_stages.py).  32 work-items per polynomial, 8 polynomials per
+// workgroup, coefficients 8t..8t+7 per work-item, like everything else in this file.
+
+// ref/cbd.c:58-107 (poly_cbd_eta1 / eta2): buf = ETA*64 bytes per polynomial, at stride bstride
+template <int ETA>
+__global__ void __launch_bounds__(256) k_st_cbd(long npoly, int16_t* r, const uint8_t* buf, size_t bstride) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int c[8];
+  cbd_contig<ETA>(buf + (size_t)pi * bstride, w.t, c);
+  lds_put_contig(r + pi * 256, w.t, c);
+}
+// the same on the PRF kernel's output layout: job (inst, nonce) at (inst * nnonce + nonce) * PRF_STRIDE,
+// eta1 for nonce < n_eta1 and eta2 = 2 above (ref/poly.c:208-232 as ref/indcpa.c:223-226,279-283 call it)
+template <class P>
+__global__ void __launch_bounds__(256) k_st_noise(long njobs, int nnonce, int n_eta1, int16_t* r, const uint8_t* prf) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= njobs) return;
+  const int nonce = (int)(pi % nnonce);
+  int c[8];
+  if (P::ETA1 == 3 && nonce < n_eta1) cbd_contig<3>(prf + (size_t)pi * P::PRF_STRIDE, w.t, c);
+  else cbd_contig<2>(prf + (size_t)pi * P::PRF_STRIDE, w.t, c);
+  lds_put_contig(r + pi * 256, w.t, c);
+}
+// ref/poly.c:111-126 / :138-145
+__global__ void __launch_bounds__(256) k_st_tobytes(long npoly, uint8_t* out, const int16_t* a) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int c[8];
+  ld_coef8(a + pi * 256, w.t, c);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)pi * 384) + 3 * w.t;
+  tobytes12(c, o[0], o[1], o[2]);
+}
+__global__ void __launch_bounds__(256) k_st_frombytes(long npoly, int16_t* r, const uint8_t* in) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(in + (size_t)pi * 384) + 3 * w.t;
+  int c[8];
+  frombytes12(p[0], p[1], p[2], c);
+  lds_put_contig(r + pi * 256, w.t, c);
+}
+// d-bit compression as the KEM kernels do it: one FMA per coefficient (fcompress), then the bit packer.
+// D = 4, 5: ref/poly.c:18-58; D = 10, 11: ref/polyvec.c:15-64 (per polynomial); D = 1: poly_tomsg, ref/poly.c:180-194
+template <int D>
+__global__ void __launch_bounds__(256) k_st_compress(long npoly, uint8_t* out, const int16_t* a) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int c[8];
+  ld_coef8(a + pi * 256, w.t, c);
+  unsigned v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = fcompress<D>((float)c[k]);
+  if constexpr (D == 1) {
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) b |= v[k] << k;
+    out[(size_t)pi * 32 + w.t] = (uint8_t)b;
+  } else {
+    pack_bits_contig<D>(out + (size_t)pi * 32 * D, w.t, v);
+  }
+}
+// ref/poly.c:70-100, ref/polyvec.c:76-115; D = 1: poly_frommsg, ref/poly.c:155-170
+template <int D>
+__global__ void __launch_bounds__(256) k_st_decompress(long npoly, int16_t* r, const uint8_t* in) {
+  const Grp w = grp();
+  const long pi = (long)blockIdx.x * 8 + w.g;
+  if (pi >= npoly) return;
+  int c[8];
+  if constexpr (D == 1) frommsg_contig(in[(size_t)pi * 32 + w.t], c);
+  else decompress_contig<D>(in + (size_t)pi * 32 * D, w.t, c);
+  lds_put_contig(r + pi * 256, w.t, c);
+}
+// sum_j a_j o b_j over K polynomial pairs on the fp32 engine, exactly as k_enc_arith accumulates a
+// matrix row against the cached r^: a canonical in [0, q) (matrix entries), b centred (|b| <= 1665,
+// an NTT output), result the centred residue of the PLAIN product -- the reference's
+// polyvec_basemul_acc_montgomery (ref/polyvec.c:189-201) carries a factor 2^-16 on top, so the test
+// compares r * 2^-16 mod q.
+template <int K>
+__global__ void __launch_bounds__(256) k_st_basemul_acc(long nvec, int16_t* r, const int16_t* a, const int16_t* b) {
+  __shared__ float ztab[128];
+  const Grp w = grp();
+  f_twiddles_to_lds(ztab);
+  const long vi = (long)blockIdx.x * 8 + w.g;
+  if (vi >= nvec) return;
+  using G = FcGroups<K>;
+  FCache bc[K];
+  float corr[G::N][8], acc[8];
+#pragma unroll
+  for (int g = 0; g < G::N; g++) {
+    float S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = G::begin(g); j < G::end(g); j++) {
+      int c[8];
+      float f[8];
+      ld_coef8(b + (vi * K + j) * 256, w.t, c);
+      i2f8(c, f);
+      f_cache_make(bc[j], f, ztab, w.t);
+      f_cache_sum(S, bc[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) corr[g][k] = f_corr(S[k]);
+  }
+#pragma unroll
+  for (int g = 0; g < G::N; g++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = (g == 0) ? corr[0][k] : fred(acc[k]) + corr[g][k];
+#pragma unroll
+    for (int j = G::begin(g); j < G::end(g); j++) {
+      float f[8];
+      u16x8_to_f(*reinterpret_cast<const uint4*>(a + (vi * K + j) * 256 + 8 * w.t), f);
+      f_mac(acc, f, bc[j]);
+    }
+  }
+  int c[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = (int)fred(acc[k]);
+  lds_put_contig(r + vi * 256, w.t, c);
+}
+
 }  // namespace ky

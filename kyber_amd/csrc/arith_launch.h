@@ -23,4 +23,14 @@ void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r);
 void launch_poly_basemul(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
 void launch_poly_mul_fused(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
 
+// single-function stages (tests/test_gpu_stages.py); eta / d / k outside the supported sets return false
+bool launch_st_cbd(hipStream_t st, int eta, size_t npoly, int16_t* r, const uint8_t* buf);
+template <class P>
+void launch_st_noise(hipStream_t st, size_t njobs, int nnonce, int n_eta1, int16_t* r, const uint8_t* prf);
+void launch_st_tobytes(hipStream_t st, size_t npoly, uint8_t* out, const int16_t* a);
+void launch_st_frombytes(hipStream_t st, size_t npoly, int16_t* r, const uint8_t* in);
+bool launch_st_compress(hipStream_t st, int d, size_t npoly, uint8_t* out, const int16_t* a);
+bool launch_st_decompress(hipStream_t st, int d, size_t npoly, int16_t* r, const uint8_t* in);
+bool launch_st_basemul_acc(hipStream_t st, int k, size_t nvec, int16_t* r, const int16_t* a, const int16_t* b);
+
 }  // namespace ky

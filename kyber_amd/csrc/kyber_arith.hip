@@ -49,4 +49,56 @@ void launch_poly_mul_fused(hipStream_t st, size_t npoly, int16_t* r, const int16
   k_poly_mul_fused<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r, a, b);
 }
 
+// ---- single-function stages ----
+bool launch_st_cbd(hipStream_t st, int eta, size_t npoly, int16_t* r, const uint8_t* buf) {
+  if (eta == 2) k_st_cbd<2><<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, buf, 128);
+  else if (eta == 3) k_st_cbd<3><<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, buf, 192);
+  else return false;
+  return true;
+}
+template <class P>
+void launch_st_noise(hipStream_t st, size_t njobs, int nnonce, int n_eta1, int16_t* r, const uint8_t* prf) {
+  k_st_noise<P><<<nblocks(njobs, 8), 256, 0, st>>>((long)njobs, nnonce, n_eta1, r, prf);
+}
+template void launch_st_noise<Par<2>>(hipStream_t, size_t, int, int, int16_t*, const uint8_t*);
+template void launch_st_noise<Par<3>>(hipStream_t, size_t, int, int, int16_t*, const uint8_t*);
+template void launch_st_noise<Par<4>>(hipStream_t, size_t, int, int, int16_t*, const uint8_t*);
+void launch_st_tobytes(hipStream_t st, size_t npoly, uint8_t* out, const int16_t* a) {
+  k_st_tobytes<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, out, a);
+}
+void launch_st_frombytes(hipStream_t st, size_t npoly, int16_t* r, const uint8_t* in) {
+  k_st_frombytes<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, in);
+}
+bool launch_st_compress(hipStream_t st, int d, size_t npoly, uint8_t* out, const int16_t* a) {
+  const unsigned nb = nblocks(npoly, 8);
+  switch (d) {
+    case 1: k_st_compress<1><<<nb, 256, 0, st>>>((long)npoly, out, a); return true;
+    case 4: k_st_compress<4><<<nb, 256, 0, st>>>((long)npoly, out, a); return true;
+    case 5: k_st_compress<5><<<nb, 256, 0, st>>>((long)npoly, out, a); return true;
+    case 10: k_st_compress<10><<<nb, 256, 0, st>>>((long)npoly, out, a); return true;
+    case 11: k_st_compress<11><<<nb, 256, 0, st>>>((long)npoly, out, a); return true;
+  }
+  return false;
+}
+bool launch_st_decompress(hipStream_t st, int d, size_t npoly, int16_t* r, const uint8_t* in) {
+  const unsigned nb = nblocks(npoly, 8);
+  switch (d) {
+    case 1: k_st_decompress<1><<<nb, 256, 0, st>>>((long)npoly, r, in); return true;
+    case 4: k_st_decompress<4><<<nb, 256, 0, st>>>((long)npoly, r, in); return true;
+    case 5: k_st_decompress<5><<<nb, 256, 0, st>>>((long)npoly, r, in); return true;
+    case 10: k_st_decompress<10><<<nb, 256, 0, st>>>((long)npoly, r, in); return true;
+    case 11: k_st_decompress<11><<<nb, 256, 0, st>>>((long)npoly, r, in); return true;
+  }
+  return false;
+}
+bool launch_st_basemul_acc(hipStream_t st, int k, size_t nvec, int16_t* r, const int16_t* a, const int16_t* b) {
+  const unsigned nb = nblocks(nvec, 8);
+  switch (k) {
+    case 2: k_st_basemul_acc<2><<<nb, 256, 0, st>>>((long)nvec, r, a, b); return true;
+    case 3: k_st_basemul_acc<3><<<nb, 256, 0, st>>>((long)nvec, r, a, b); return true;
+    case 4: k_st_basemul_acc<4><<<nb, 256, 0, st>>>((long)nvec, r, a, b); return true;
+  }
+  return false;
+}
+
 }  // namespace ky

@@ -519,6 +519,24 @@ inline int copy_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spi
   return 0;
 }
 
+// Noise polynomials for nonces 0..nnonce-1 of every seed: the PRF kernel of the KEM pipelines
+// followed by the centred binomial map (ref/poly.c:208-232), r[i][nonce][256].
+template <class P, bool N90>
+int getnoise_dev(size_t n, int nnonce, int n_eta1, int16_t* r, const uint8_t* seeds, hipStream_t st) {
+  if (nnonce < 1 || nnonce > 256 || n_eta1 < 0 || n * (size_t)nnonce > 0x7fffffffu) return KYBER_HIP_EINVAL;
+  const size_t jobs = n * (size_t)nnonce;
+  AsyncBuf small, prf;
+  if (int rc = small.alloc(n * SMALL, st)) return rc;
+  if (int rc = prf.alloc(jobs * P::PRF_STRIDE, st)) return rc;
+  if (int rc = copy_rows(small.p, SMALL, seeds, 32, 32, n, st)) return rc;
+  if constexpr (N90)
+    RUN("k90_prf", st, k90_prf<P><<<blocks(jobs, 256), 256, 0, st>>>((int)n, nnonce, n_eta1, small.p, 0, prf.p));
+  else
+    RUN("k_prf", st, k_prf<P><<<blocks(jobs, sponge_wg(jobs)), sponge_wg(jobs), 0, st>>>((int)n, nnonce, n_eta1, small.p, 0, prf.p));
+  RUN("k_st_noise", st, launch_st_noise<P>(st, jobs, nnonce, n_eta1, r, prf.p));
+  return 0;
+}
+
 template <int NP, bool N90>
 int kdf_parts(size_t n, const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, uint8_t* out, hipStream_t st) {
   RUN("k_kdf_parts", st, k_kdf_parts<NP, N90><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, p0, p1, p2, out));
@@ -1150,6 +1168,50 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, cons
   if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, gen_matrix_dev, n, mat, seeds, transposed, st);
+}
+
+int kyber_batch_getnoise_dev(int k, int nineties, size_t n, int nnonce, int n_eta1, int16_t* r, const uint8_t* seeds, void* stream) {
+  if (!r || !seeds) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, getnoise_dev, n, nnonce, n_eta1, r, seeds, st);
+}
+int kyber_batch_poly_cbd_dev(int eta, size_t npoly, int16_t* r, const uint8_t* buf, void* stream) {
+  if (!r || !buf || (eta != 2 && eta != 3)) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_st_cbd", static_cast<hipStream_t>(stream), (void)launch_st_cbd(static_cast<hipStream_t>(stream), eta, npoly, r, buf));
+  return 0;
+}
+int kyber_batch_poly_tobytes_dev(size_t npoly, uint8_t* r, const int16_t* a, void* stream) {
+  if (!r || !a) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_st_tobytes", static_cast<hipStream_t>(stream), launch_st_tobytes(static_cast<hipStream_t>(stream), npoly, r, a));
+  return 0;
+}
+int kyber_batch_poly_frombytes_dev(size_t npoly, int16_t* r, const uint8_t* a, void* stream) {
+  if (!r || !a) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_st_frombytes", static_cast<hipStream_t>(stream), launch_st_frombytes(static_cast<hipStream_t>(stream), npoly, r, a));
+  return 0;
+}
+static bool codec_bits_ok(int d) { return d == 1 || d == 4 || d == 5 || d == 10 || d == 11; }
+int kyber_batch_poly_compress_dev(int d, size_t npoly, uint8_t* r, const int16_t* a, void* stream) {
+  if (!r || !a || !codec_bits_ok(d)) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_st_compress", static_cast<hipStream_t>(stream), (void)launch_st_compress(static_cast<hipStream_t>(stream), d, npoly, r, a));
+  return 0;
+}
+int kyber_batch_poly_decompress_dev(int d, size_t npoly, int16_t* r, const uint8_t* a, void* stream) {
+  if (!r || !a || !codec_bits_ok(d)) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_st_decompress", static_cast<hipStream_t>(stream), (void)launch_st_decompress(static_cast<hipStream_t>(stream), d, npoly, r, a));
+  return 0;
+}
+int kyber_batch_polyvec_basemul_acc_dev(int k, size_t nvec, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
+  if (!r || !a || !b || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (!nvec) return 0;
+  RUN("k_st_basemul_acc", static_cast<hipStream_t>(stream), (void)launch_st_basemul_acc(static_cast<hipStream_t>(stream), k, nvec, r, a, b));
+  return 0;
 }
 
 int kyber_batch_poly_ntt_dev(size_t npoly, int16_t* r, void* stream) {

@@ -88,6 +88,13 @@ def library():
         "kyber_batch_enc_shared_pk_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_shared_sk_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
+        "kyber_batch_getnoise_dev": [ci, ci, sz, ci, ci, i16p, u8p, vp],
+        "kyber_batch_poly_cbd_dev": [ci, sz, i16p, u8p, vp],
+        "kyber_batch_poly_tobytes_dev": [sz, u8p, i16p, vp],
+        "kyber_batch_poly_frombytes_dev": [sz, i16p, u8p, vp],
+        "kyber_batch_poly_compress_dev": [ci, sz, u8p, i16p, vp],
+        "kyber_batch_poly_decompress_dev": [ci, sz, i16p, u8p, vp],
+        "kyber_batch_polyvec_basemul_acc_dev": [ci, sz, i16p, i16p, i16p, vp],
         "kyber_batch_poly_ntt_dev": [sz, i16p, vp],
         "kyber_batch_poly_invntt_dev": [sz, i16p, vp],
         "kyber_batch_poly_basemul_dev": [sz, i16p, i16p, i16p, vp],
@@ -501,4 +508,66 @@ def poly_basemul(r, a, b):
 
 def poly_mul_fused(r, a, b):
     _poly_call("kyber_batch_poly_mul_fused_dev", r, a, b)
+    return r
+
+
+# ---- single-function stages (include/kyber_batch.h), torch tensors on the GPU ----
+def getnoise(k, nineties, seeds, nnonce, n_eta1):
+    """seeds uint8[n,32] -> int16[n, nnonce, 256]: poly_getnoise for nonces 0..nnonce-1 (ref/poly.c:208-232)."""
+    import torch
+    n = seeds.numel() // 32
+    r = torch.empty((n, nnonce, 256), dtype=torch.int16, device=seeds.device)
+    _check(library().kyber_batch_getnoise_dev(k, int(nineties), n, nnonce, n_eta1, _tptr(r, r.numel() * 2, "r"),
+                                              _tptr(seeds, n * 32, "seeds"), _torch_stream()), "kyber_batch_getnoise_dev")
+    return r
+
+
+def poly_cbd(eta, buf):
+    """buf uint8[npoly, 64*eta] -> int16[npoly,256] (ref/cbd.c:58-107)."""
+    import torch
+    npoly = buf.numel() // (64 * eta)
+    r = torch.empty((npoly, 256), dtype=torch.int16, device=buf.device)
+    _check(library().kyber_batch_poly_cbd_dev(eta, npoly, _tptr(r, npoly * 512, "r"), _tptr(buf, npoly * 64 * eta, "buf"),
+                                              _torch_stream()), "kyber_batch_poly_cbd_dev")
+    return r
+
+
+def _codec(name, d, src, out_shape, out_dtype, in_bytes, out_bytes):
+    import torch
+    npoly = src.shape[0]
+    out = torch.empty((npoly,) + out_shape, dtype=out_dtype, device=src.device)
+    fn = getattr(library(), name)
+    args = ([d] if d is not None else []) + [npoly, _tptr(out, npoly * out_bytes, "out"), _tptr(src, npoly * in_bytes, "in"), _torch_stream()]
+    _check(fn(*args), name)
+    return out
+
+
+def poly_tobytes(a):
+    import torch
+    return _codec("kyber_batch_poly_tobytes_dev", None, a, (384,), torch.uint8, 512, 384)
+
+
+def poly_frombytes(b):
+    import torch
+    return _codec("kyber_batch_poly_frombytes_dev", None, b, (256,), torch.int16, 384, 512)
+
+
+def poly_compress(d, a):
+    import torch
+    return _codec("kyber_batch_poly_compress_dev", d, a, (32 * d,), torch.uint8, 512, 32 * d)
+
+
+def poly_decompress(d, b):
+    import torch
+    return _codec("kyber_batch_poly_decompress_dev", d, b, (256,), torch.int16, 32 * d, 512)
+
+
+def polyvec_basemul_acc(k, a, b):
+    """a, b int16[nvec, k, 256] -> int16[nvec, 256], plain (non-Montgomery) residues; see the header."""
+    import torch
+    nvec = a.shape[0]
+    r = torch.empty((nvec, 256), dtype=torch.int16, device=a.device)
+    _check(library().kyber_batch_polyvec_basemul_acc_dev(k, nvec, _tptr(r, nvec * 512, "r"), _tptr(a, nvec * k * 512, "a"),
+                                                         _tptr(b, nvec * k * 512, "b"), _torch_stream()),
+           "kyber_batch_polyvec_basemul_acc_dev")
     return r

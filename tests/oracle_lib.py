@@ -200,6 +200,40 @@ class Oracle:
             fn(_p(row))
         return r
 
+    def getnoise(self, k, nineties, eta, seed, nonce):
+        p = self.params(k, nineties)
+        seed = np.ascontiguousarray(seed, np.uint8)
+        r = np.empty(256, np.int16)
+        self.lib.ko_getnoise(ctypes.byref(p), int(eta), _p(r), _p(seed), int(nonce))
+        return r
+
+    def cbd(self, eta, buf):
+        buf = np.ascontiguousarray(buf, np.uint8).reshape(-1, 64 * eta)
+        r = np.empty((buf.shape[0], 256), np.int16)
+        for i in range(buf.shape[0]):
+            self.lib.ko_cbd(int(eta), _p(r[i]), _p(buf[i]))
+        return r
+
+    def codec(self, name, src, out_shape, out_dtype, d=None):
+        """ko_poly_{tobytes,frombytes,compress,decompress,frommsg,tomsg} row by row."""
+        src = np.ascontiguousarray(src)
+        out = np.empty((src.shape[0],) + out_shape, out_dtype)
+        fn = getattr(self.lib, name)
+        for i in range(src.shape[0]):
+            if d is None:
+                fn(_p(out[i]), _p(src[i]))
+            else:
+                fn(int(d), _p(out[i]), _p(src[i]))
+        return out
+
+    def polyvec_basemul_acc(self, k, a, b):
+        a = np.ascontiguousarray(a, np.int16).reshape(-1, k, 256)
+        b = np.ascontiguousarray(b, np.int16).reshape(-1, k, 256)
+        r = np.empty((a.shape[0], 256), np.int16)
+        for i in range(a.shape[0]):
+            self.lib.ko_polyvec_basemul_acc(int(k), _p(r[i]), _p(a[i]), _p(b[i]))
+        return r
+
     def poly_basemul(self, a, b):
         a = np.ascontiguousarray(a, np.int16).reshape(-1, 256)
         b = np.ascontiguousarray(b, np.int16).reshape(-1, 256)

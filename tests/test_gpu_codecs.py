@@ -1,0 +1,129 @@
+"""GPU: the single-function stages of include/kyber_batch.h -- noise (PRF + centred binomial
+map), the 12-bit and d-bit codecs, message encoding, and the accumulated base multiplication --
+each against the oracle's restatement of the reference function (a7, a11, a13-a17).
+The kernels are built from the device functions the KEM kernels use, so a KEM parity failure
+can be localised here."""
+import numpy as np
+import pytest
+import torch
+
+from kyber_amd import lib as kl
+
+pytestmark = pytest.mark.gpu
+Q = 3329
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("k,n90", [(2, 0), (3, 0), (4, 0), (2, 1), (3, 1)])
+def test_getnoise_matches_oracle(oracle, k, n90):
+    """ref/poly.c:208-232: eta1 (3 for Kyber512) below nonce K, eta2 = 2 from there, as indcpa_enc draws them."""
+    rng = np.random.default_rng(50 + k + n90)
+    n, nnonce = 37, 2 * k + 1
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    got = kl.getnoise(k, n90, _dev(seeds), nnonce, k).cpu().numpy()
+    eta1 = 3 if k == 2 else 2
+    for i in range(0, n, 5):
+        for nonce in range(nnonce):
+            want = oracle.getnoise(k, n90, eta1 if nonce < k else 2, seeds[i], nonce)
+            assert np.array_equal(got[i, nonce], want), (i, nonce)
+    # key generation's use: every nonce with eta1 (ref/indcpa.c:223-226)
+    got = kl.getnoise(k, n90, _dev(seeds), 2 * k, 2 * k).cpu().numpy()
+    assert np.array_equal(got[3, 2 * k - 1], oracle.getnoise(k, n90, eta1, seeds[3], 2 * k - 1))
+
+
+@pytest.mark.parametrize("eta", [2, 3])
+def test_cbd_matches_oracle_including_extremes(oracle, eta):
+    rng = np.random.default_rng(eta)
+    buf = rng.integers(0, 256, (101, 64 * eta), dtype=np.uint8)
+    buf[0], buf[1], buf[2] = 0x00, 0xFF, 0x55
+    got = kl.poly_cbd(eta, _dev(buf)).cpu().numpy()
+    assert np.array_equal(got, oracle.cbd(eta, buf))
+    assert got.min() >= -eta and got.max() <= eta
+
+
+def test_tobytes_frombytes_match_oracle(oracle):
+    rng = np.random.default_rng(7)
+    a = rng.integers(-(Q - 1), Q, (67, 256)).astype(np.int16)      # any representative in (-q, q): ref/poly.c:118-121
+    a[0], a[1], a[2] = Q - 1, -(Q - 1), 0
+    got = kl.poly_tobytes(_dev(a)).cpu().numpy()
+    assert np.array_equal(got, oracle.codec("ko_poly_tobytes", a, (384,), np.uint8))
+    b = rng.integers(0, 256, (67, 384), dtype=np.uint8)            # frombytes masks 12 bits and nothing else: values up to 4095
+    b[0] = 0xFF
+    got = kl.poly_frombytes(_dev(b)).cpu().numpy()
+    assert np.array_equal(got, oracle.codec("ko_poly_frombytes", b, (256,), np.int16))
+    assert got.max() == 4095
+
+
+@pytest.mark.parametrize("d", [4, 5, 10, 11])
+def test_compress_decompress_match_oracle(oracle, d):
+    rng = np.random.default_rng(d)
+    a = rng.integers(-(Q - 1), Q, (75, 256)).astype(np.int16)
+    a[0] = np.arange(256) * 13 % Q
+    a[1] = -(np.arange(256) * 13 % Q)
+    a[2, :] = np.resize(np.array([1664, 1665, -1664, -1665, Q - 1, 1 - Q, 0, 1], np.int16), 256)
+    got = kl.poly_compress(d, _dev(a)).cpu().numpy()
+    assert np.array_equal(got, oracle.codec("ko_poly_compress", a, (32 * d,), np.uint8, d))
+    b = rng.integers(0, 256, (75, 32 * d), dtype=np.uint8)
+    b[0], b[1] = 0xFF, 0x00
+    got = kl.poly_decompress(d, _dev(b)).cpu().numpy()
+    assert np.array_equal(got, oracle.codec("ko_poly_decompress", b, (256,), np.int16, d))
+
+
+def test_every_residue_compresses_like_the_reference(oracle):
+    """all 2q - 1 representatives in (-q, q), every d: the one-FMA compression of fpoly.h on the GPU itself"""
+    vals = np.arange(-(Q - 1), Q, dtype=np.int16)
+    a = np.resize(vals, (27, 256)).astype(np.int16)
+    for d in (1, 4, 5, 10, 11):
+        got = kl.poly_compress(d, _dev(a)).cpu().numpy()
+        if d == 1:
+            want = oracle.codec("ko_poly_tomsg", a, (32,), np.uint8)
+        else:
+            want = oracle.codec("ko_poly_compress", a, (32 * d,), np.uint8, d)
+        assert np.array_equal(got, want), d
+
+
+def test_message_encoding_matches_oracle(oracle):
+    rng = np.random.default_rng(9)
+    msg = rng.integers(0, 256, (41, 32), dtype=np.uint8)
+    msg[0], msg[1] = 0xFF, 0x00
+    got = kl.poly_decompress(1, _dev(msg)).cpu().numpy()                 # poly_frommsg
+    assert np.array_equal(got, oracle.codec("ko_poly_frommsg", msg, (256,), np.int16))
+    a = rng.integers(-(Q - 1), Q, (41, 256)).astype(np.int16)
+    a[0, :] = np.resize(np.array([832, 833, 2496, 2497, -832, -833, -2496, -2497], np.int16), 256)  # the rounding boundaries q/4, 3q/4
+    got = kl.poly_compress(1, _dev(a)).cpu().numpy()                     # poly_tomsg
+    assert np.array_equal(got, oracle.codec("ko_poly_tomsg", a, (32,), np.uint8))
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_polyvec_basemul_acc_matches_oracle_mod_q(oracle, k):
+    """The fp32 accumulation of k_enc_arith (cached multiplicand, unreduced FMA chains, offset
+    correction) against ref/polyvec.c:189-201: the reference's result carries 2^-16 (Montgomery
+    products), the kernel's does not, so r_ref * 2^16 = r_gpu mod q."""
+    rng = np.random.default_rng(30 + k)
+    nvec = 53
+    a = rng.integers(0, Q, (nvec, k, 256)).astype(np.int16)               # canonical, as the matrix sampler writes them
+    b = rng.integers(-1664, 1665, (nvec, k, 256)).astype(np.int16)        # centred, as an NTT leaves them
+    a[0], b[0] = Q - 1, 1664                                               # the accumulation bound of fpoly.h, every term positive
+    a[1], b[1] = Q - 1, -1664
+    a[2, :, 0::2], a[2, :, 1::2], b[2] = Q - 1, 0, 1664
+    got = kl.polyvec_basemul_acc(k, _dev(a), _dev(b)).cpu().numpy().astype(np.int64)
+    want = oracle.polyvec_basemul_acc(k, a, b).astype(np.int64)
+    assert np.abs(got).max() <= 1665
+    assert np.all((want * 65536 - got) % Q == 0)
+
+
+def test_stage_entry_points_reject_bad_arguments():
+    import ctypes
+    L = kl.library()
+    x = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    p = ctypes.c_void_p(x.data_ptr())
+    assert L.kyber_batch_poly_cbd_dev(4, 1, p, p, None) == -1
+    assert L.kyber_batch_poly_compress_dev(3, 1, p, p, None) == -1
+    assert L.kyber_batch_poly_decompress_dev(12, 1, p, p, None) == -1
+    assert L.kyber_batch_polyvec_basemul_acc_dev(5, 1, p, p, p, None) == -1
+    assert L.kyber_batch_getnoise_dev(3, 0, 1, 0, 0, p, p, None) == -1
+    assert L.kyber_batch_poly_tobytes_dev(0, p, p, None) == 0
+    assert L.kyber_batch_poly_frombytes_dev(1, None, p, None) == -1
