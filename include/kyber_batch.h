@@ -190,6 +190,11 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t *r, const int16_t *a, c
  * gen_matrix: mat[i][e][256] int16, e = row*k + col of A (transposed = 0) or
  * A^T (transposed = 1) expanded from seeds[i][32].        ref/indcpa.c:164-192 */
 int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, const uint8_t *seeds, int transposed, void *stream);
+/* keccak_f1600: the permutation on n states of 25 little-endian 64-bit words, in place.   ref/fips202.c:82-344
+ * hash_h: out[i][32] = H(in[i]) with in[i] one public key (of_ct = 0) or one ciphertext (of_ct = 1) of
+ * the set: sha3_256, or sha256 for the 90s sets (ref/symmetric.h:27,50), through the FO kernels' absorb loops */
+int kyber_batch_keccak_f1600_dev(size_t n, uint64_t *states, void *stream);
+int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t *out, const uint8_t *in, void *stream);
 /* getnoise: r[i][nonce][256] = poly_getnoise(seeds[i], nonce) for nonce = 0..nnonce-1, with eta1 for
  * nonce < n_eta1 and eta2 above -- the PRF kernel of the KEM pipelines followed by the centred
  * binomial map.                      ref/poly.c:208-232, ref/symmetric-shake.c:43-51 / symmetric-aes.c:15-20

@@ -262,4 +262,37 @@ __global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_
   }
 }
 
+// ------------------------------------------------------------------ hash stages (tests)
+// the permutation alone on n states of 25 little-endian 64-bit words     ref/fips202.c:82-344
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_st_keccak_f1600(int n, uint64_t* __restrict__ st) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64p A[25];
+  uint64_t* s = st + (size_t)i * 25;
+#pragma unroll
+  for (int w = 0; w < 25; w++) A[w] = mk64(s[w]);
+  keccak_f1600(A);
+#pragma unroll
+  for (int w = 0; w < 25; w++) s[w] = to64(A[w]);
+}
+// H of one pk (CT = false) or one ciphertext (CT = true) per work-item: sha3_256 or, for the 90s
+// sets, sha256 (ref/symmetric.h:27,50), through the absorb loops of the FO kernels
+template <class P, bool N90, bool CT>
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_st_hash_h(int n, const uint8_t* __restrict__ in, uint8_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int LEN = CT ? P::CTB : P::PKB;
+  if constexpr (N90) {
+    uint32_t h[8];
+    u64p hp[4];
+    sha256_global<LEN>(in + (size_t)i * LEN, h);
+    sha256_digest_le(h, hp);
+    st32Bv(out + (size_t)i * 32, hp);
+  } else {
+    u64p A[25];
+    keccak_absorb_words<136, 0x06, LEN>(A, in + (size_t)i * LEN);
+    st32B(out + (size_t)i * 32, A[0], A[1], A[2], A[3]);
+  }
+}
+
 }  // namespace ky

@@ -519,6 +519,14 @@ inline int copy_rows(uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spi
   return 0;
 }
 
+template <class P, bool N90>
+int hash_h_dev(size_t n, int of_ct, uint8_t* out, const uint8_t* in, hipStream_t st) {
+  if (n > 0x7fffffffu) return KYBER_HIP_EINVAL;
+  if (of_ct) RUN("k_st_hash_h", st, (k_st_hash_h<P, N90, true><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, in, out)));
+  else RUN("k_st_hash_h", st, (k_st_hash_h<P, N90, false><<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, in, out)));
+  return 0;
+}
+
 // Noise polynomials for nonces 0..nnonce-1 of every seed: the PRF kernel of the KEM pipelines
 // followed by the centred binomial map (ref/poly.c:208-232), r[i][nonce][256].
 template <class P, bool N90>
@@ -1170,6 +1178,19 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t* mat, cons
   DISPATCH(k, nineties, gen_matrix_dev, n, mat, seeds, transposed, st);
 }
 
+int kyber_batch_keccak_f1600_dev(size_t n, uint64_t* states, void* stream) {
+  if (!states || n > 0x7fffffffu) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RUN("k_st_keccak_f1600", st, k_st_keccak_f1600<<<blocks(n, sponge_wg(n)), sponge_wg(n), 0, st>>>((int)n, states));
+  return 0;
+}
+int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t* out, const uint8_t* in, void* stream) {
+  if (!out || !in) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH(k, nineties, hash_h_dev, n, of_ct, out, in, st);
+}
 int kyber_batch_getnoise_dev(int k, int nineties, size_t n, int nnonce, int n_eta1, int16_t* r, const uint8_t* seeds, void* stream) {
   if (!r || !seeds) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;

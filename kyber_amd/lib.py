@@ -88,6 +88,8 @@ def library():
         "kyber_batch_enc_shared_pk_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_shared_sk_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
+        "kyber_batch_keccak_f1600_dev": [sz, vp, vp],
+        "kyber_batch_hash_h_dev": [ci, ci, sz, ci, u8p, u8p, vp],
         "kyber_batch_getnoise_dev": [ci, ci, sz, ci, ci, i16p, u8p, vp],
         "kyber_batch_poly_cbd_dev": [ci, sz, i16p, u8p, vp],
         "kyber_batch_poly_tobytes_dev": [sz, u8p, i16p, vp],
@@ -571,3 +573,20 @@ def polyvec_basemul_acc(k, a, b):
                                                          _tptr(b, nvec * k * 512, "b"), _torch_stream()),
            "kyber_batch_polyvec_basemul_acc_dev")
     return r
+
+
+def keccak_f1600_(states):
+    """int64/uint64 tensor [n,25] on the GPU, permuted in place (ref/fips202.c:82-344)."""
+    n = states.numel() // 25
+    _check(library().kyber_batch_keccak_f1600_dev(n, ctypes.c_void_p(states.data_ptr()), _torch_stream()), "kyber_batch_keccak_f1600_dev")
+    return states
+
+
+def hash_h(k, nineties, data, of_ct):
+    """uint8[n, PKB or CTB] -> uint8[n,32]: sha3_256 / sha256 as the FO kernels compute it."""
+    import torch
+    n = data.shape[0]
+    out = torch.empty((n, 32), dtype=torch.uint8, device=data.device)
+    _check(library().kyber_batch_hash_h_dev(k, int(nineties), n, int(bool(of_ct)), _tptr(out, n * 32, "out"),
+                                            _tptr(data, data.numel(), "in"), _torch_stream()), "kyber_batch_hash_h_dev")
+    return out

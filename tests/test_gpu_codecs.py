@@ -127,3 +127,43 @@ def test_stage_entry_points_reject_bad_arguments():
     assert L.kyber_batch_getnoise_dev(3, 0, 1, 0, 0, p, p, None) == -1
     assert L.kyber_batch_poly_tobytes_dev(0, p, p, None) == 0
     assert L.kyber_batch_poly_frombytes_dev(1, None, p, None) == -1
+
+
+def test_keccak_f1600_matches_oracle(oracle):
+    """ref/fips202.c:82-344 on the GPU's (lo, hi) halves with the phase-locked schedule: zero state
+    (the published first lane F1258F7940E1DDE7), all-ones, random; a ragged count of states."""
+    import ctypes
+    rng = np.random.default_rng(1600)
+    n = 1000
+    st = rng.integers(0, 1 << 63, (n, 25), dtype=np.int64) * 2 + rng.integers(0, 2, (n, 25), dtype=np.int64)
+    st[0] = 0
+    st[1] = -1
+    want = st.copy()
+    for i in list(range(8)) + list(range(8, n, 97)) + [n - 1]:
+        row = np.ascontiguousarray(want[i])
+        oracle.lib.ko_keccak_f1600(ctypes.c_void_p(row.ctypes.data))
+        want[i] = row
+    got = kl.keccak_f1600_(_dev(st)).cpu().numpy()
+    assert got[0, 0] == np.int64(np.uint64(0xF1258F7940E1DDE7).astype(np.int64))
+    for i in list(range(8)) + list(range(8, n, 97)) + [n - 1]:
+        assert np.array_equal(got[i], want[i]), i
+
+
+@pytest.mark.parametrize("k,n90", [(2, 0), (3, 0), (4, 0), (3, 1), (4, 1)])
+def test_hash_h_of_keys_and_ciphertexts_matches_oracle(oracle, k, n90):
+    """H = sha3_256 (sha256 for the 90s sets) over pk- and ct-sized inputs: the multi-block absorb
+    loops of the FO kernels (with their next-block prefetch) on their own."""
+    import ctypes
+    p = oracle.params(k, n90)
+    rng = np.random.default_rng(k + 10 * n90)
+    fn = oracle.lib.ko_sha256 if n90 else oracle.lib.ko_sha3_256
+    for of_ct, size in ((0, oracle.lib.ko_pk_bytes(ctypes.byref(p))), (1, oracle.lib.ko_ct_bytes(ctypes.byref(p)))):
+        n = 77
+        data = rng.integers(0, 256, (n, size), dtype=np.uint8)
+        data[0], data[1] = 0x00, 0xFF
+        got = kl.hash_h(k, n90, _dev(data), of_ct).cpu().numpy()
+        for i in range(0, n, 4):
+            h = np.empty(32, np.uint8)
+            row = np.ascontiguousarray(data[i])
+            fn(ctypes.c_void_p(h.ctypes.data), ctypes.c_void_p(row.ctypes.data), size)
+            assert np.array_equal(got[i], h), (of_ct, i)
