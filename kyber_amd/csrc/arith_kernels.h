@@ -181,14 +181,12 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
   using G = FcGroups<K>;
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
-  __shared__ uint32_t bad[G_INST];
   __shared__ float ztab[128];
   const Grp w = grp();
   const int inst0 = blockIdx.x * G_INST;
   const int li = w.g;                       // G_INST == number of groups
   const int gi = min(inst0 + li, n - 1);    // surplus groups of the last workgroup recompute the last instance
   f_twiddles_to_lds(ztab);
-  if (CMP && threadIdx.x < G_INST) bad[threadIdx.x] = 0;
 
   const uint8_t* prf_i = prf + (size_t)gi * NJ * P::PRF_STRIDE;
   const int16_t* mat_i = mat + (size_t)gi * mat_stride;
@@ -310,26 +308,31 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
       pack_bits_contig<P::DV>(ctb[li] + P::UB * K, w.t, c);
     }
   }
-  __syncthreads();
-  // the workgroup's ciphertexts are one contiguous run of global memory
-  const int nvalid = min(G_INST, n - inst0);
-  const uint4* src = reinterpret_cast<const uint4*>(&ctb[0][0]);
-  uint4* dst = reinterpret_cast<uint4*>(ct + (size_t)inst0 * P::CTB);
-  for (int o = threadIdx.x; o < nvalid * (P::CTB / 16); o += 256) {
-    if constexpr (CMP) {
-      // ref/verify.c:16-25: OR-reduce of the XOR, no branch on the (secret-dependent) result --
-      // every 16-byte block issues the same LDS atomic whatever it found
-      uint4 x = src[o], y = dst[o];
-      const uint32_t d = (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
-      atomicOr(&bad[o / (P::CTB / 16)], (d | (0u - d)) >> 31);
-    } else {
-      dst[o] = src[o];
-    }
-  }
   if constexpr (CMP) {
+    // ref/verify.c:16-25: OR-reduce of the XOR, no branch on the (secret-dependent) result.  Each group
+    // compares the ciphertext it has just assembled (its own lanes wrote all of it: a wavefront-level
+    // fence is enough) with the one it was given; the 32 lanes' findings meet in a ballot, whose half
+    // for this group is non-zero exactly if some byte differs.
+    KY_WSYNC();
+    const uint4* mine = reinterpret_cast<const uint4*>(&ctb[li][0]);
+    const uint4* given = reinterpret_cast<const uint4*>(ct + (size_t)gi * P::CTB);
+    uint32_t d = 0;
+#pragma unroll
+    for (int o = 0; o < (P::CTB / 16 + 31) / 32; o++) {
+      const int b = min(w.t + 32 * o, P::CTB / 16 - 1);   // the last pass re-reads the last block instead of branching
+      const uint4 x = mine[b], y = given[b];
+      d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    const unsigned long long differ = __ballot(d != 0);
+    const uint32_t flag = (uint32_t)(differ >> (32 * (threadIdx.x >> 5 & 1))) != 0u;
+    if (w.t == 0 && inst0 + li < n) *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + li) * SMALL + 96) = flag;
+  } else {
     __syncthreads();
-    if (threadIdx.x < nvalid)
-      *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + threadIdx.x) * SMALL + 96) = bad[threadIdx.x];
+    // the workgroup's ciphertexts are one contiguous run of global memory
+    const int nvalid = min(G_INST, n - inst0);
+    const uint4* src = reinterpret_cast<const uint4*>(&ctb[0][0]);
+    uint4* dst = reinterpret_cast<uint4*>(ct + (size_t)inst0 * P::CTB);
+    for (int o = threadIdx.x; o < nvalid * (P::CTB / 16); o += 256) dst[o] = src[o];
   }
 }
 
