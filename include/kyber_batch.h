@@ -195,6 +195,12 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, cons
  * the set: sha3_256, or sha256 for the 90s sets (ref/symmetric.h:27,50), through the FO kernels' absorb loops */
 int kyber_batch_keccak_f1600_dev(size_t n, uint64_t *states, void *stream);
 int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t *out, const uint8_t *in, void *stream);
+/* aes256ctr: out[i][nblocks][16] = keystream blocks first_block .. first_block + nblocks - 1 of
+ * AES-256-CTR(keys[i][32], nonce = nonces[i] as two little-endian bytes followed by ten zero bytes), the
+ * XOF and PRF of the 90s sets: aes256ctr_init + aes256ctr_squeezeblocks / aes256ctr_prf, whose callers
+ * pass exactly such nonces.                    ref/aes256ctr.c:530-586, ref/symmetric-aes.c:7-20 */
+int kyber_batch_aes256ctr_dev(size_t n, uint8_t *out, size_t nblocks, const uint8_t *keys, const uint16_t *nonces,
+                              uint32_t first_block, void *stream);
 /* getnoise: r[i][nonce][256] = poly_getnoise(seeds[i], nonce) for nonce = 0..nnonce-1, with eta1 for
  * nonce < n_eta1 and eta2 above -- the PRF kernel of the KEM pipelines followed by the centred
  * binomial map.                      ref/poly.c:208-232, ref/symmetric-shake.c:43-51 / symmetric-aes.c:15-20

@@ -151,13 +151,13 @@ __global__ void __launch_bounds__(SPONGE_WG, 4) k_kdf_parts(int n, const uint8_t
 
 // PRF: AES-256-CTR(key = seed, nonce = {nonce,0,...}) from counter 0.
 // ref/symmetric-aes.c:15-20 -> ref/aes256ctr.c:557-563.  Jobs are nonce-major.
-template <class P>
-__global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
-                                               int seed_off, uint8_t* __restrict__ prf) {
+template <class P, int WG = AES_WG>
+__global__ void __launch_bounds__(WG) k90_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+                                              int seed_off, uint8_t* __restrict__ prf) {
   KY_AES_TABLE(tab);
   aes_table_init(tab);
   const AesLds L = aes_lds(tab);
-  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long gid = (long)blockIdx.x * WG + threadIdx.x;
   if (gid >= (long)n * njobs_per_inst) return;
   int nonce = (int)(gid / n), inst = (int)(gid % n);
   u64p key[4];
@@ -167,11 +167,14 @@ __global__ void __launch_bounds__(256) k90_prf(int n, int njobs_per_inst, int n_
   const AesCtr cx = aes256ctr_init(L, rk, (uint32_t)nonce);
   uint8_t* out = prf + ((size_t)inst * njobs_per_inst + nonce) * P::PRF_STRIDE;
   const int nblk = (P::ETA1 == 3 && nonce < n_eta1) ? 12 : 8;
+  // 8 or 12 blocks.  (Four blocks per round of stores, so that a work-item fills whole 64-byte lines back to
+  // back, changed neither the time nor WRITE_SIZE, 2.9 x the bytes: the kernel is bound by the look-ups.)
 #pragma unroll 1
-  for (int b = 0; b < nblk; b++) {
-    uint32_t o[4];
-    aes256ctr_block(L, rk, cx, (uint32_t)b, o);
-    *reinterpret_cast<uint4*>(out + 16 * b) = make_uint4(o[0], o[1], o[2], o[3]);
+  for (int b = 0; b < nblk; b += AES_NB) {
+    uint32_t o[AES_NB][4];
+    aes256ctr_blocks<AES_NB>(L, rk, cx, (uint32_t)b, o);
+#pragma unroll
+    for (int u = 0; u < AES_NB; u++) *reinterpret_cast<uint4*>(out + 16 * (b + u)) = make_uint4(o[u][0], o[u][1], o[u][2], o[u][3]);
   }
 }
 
@@ -192,6 +195,9 @@ constexpr int STAGE90_DW = (2 * XOF90_GROUPS + 2) / 2;          // 1 carry slot 
 // offset.  An aligned store may carry up to three dwords past the lane's
 // count; they lie inside the same polynomial (whose end is 16-byte aligned) and
 // are overwritten by the next piece or by the tail kernel.
+// (Rows laid out one per LDS bank, so that the diverging write cursors of the parse never conflict, were
+// measured: SQ_LDS_BANK_CONFLICT gone, the kernel's time unchanged, the parse 20 % longer by its address
+// arithmetic.  The rows stay consecutive.)
 template <int SDW>
 __device__ __forceinline__ int drain_private(uint32_t* row, long job, int c0, int c1, uint32_t* mat32) {
   const int d0 = c0 >> 1;
@@ -215,50 +221,116 @@ __device__ __forceinline__ int drain_private(uint32_t* row, long job, int c0, in
 }
 
 
-template <class P>
-__global__ void __launch_bounds__(256) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
-                                                         int transposed, int16_t* __restrict__ mat) {
+// ABLATE (tools/microbench/matrix90_ablate only): 1 no drain, 2 keystream only (no parse, no drain),
+// 3 parse and drain of a made-up keystream (no AES), 4 parse of a made-up keystream (no AES, no drain)
+template <class P, int WG = AES_WG, int ABLATE = 0>
+__global__ void __launch_bounds__(WG) k90_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                        int transposed, int16_t* __restrict__ mat) {
   KY_AES_TABLE(tab);
-  __shared__ uint32_t stage[4 * 64 * STAGE90_DW + 8];  // + 8: drain_private reads whole 16-byte groups
+  __shared__ uint32_t stage[WG * STAGE90_DW + 8];  // + 8: drain_private reads whole 16-byte groups
   aes_table_init(tab);
   const AesLds L = aes_lds(tab);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long job0 = (long)blockIdx.x * 256 + wave * 64;
-  const long job = job0 + lane;
-  const bool valid = job < njobs;
-  const long jc = valid ? job : (long)njobs - 1;
-  const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
-  const int i = e / P::K, j = e % P::K;
-  const uint32_t x = transposed ? i : j, y = transposed ? j : i;
-
-  u64p key[4];
-  uint32_t rk[60];
-  ld32B(rho + (size_t)inst * rho_stride, key);
-  aes256_expand(L, key, rk);
-  const AesCtr cx = aes256ctr_init(L, rk, x | y << 8);
-
-  uint32_t* row = stage + (wave * 64 + lane) * STAGE90_DW;
+  uint32_t* row = stage + threadIdx.x * STAGE90_DW;
   const uint32_t row_addr = lds_addr(row);
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
-  int ctr = valid ? 0 : 256;
-  uint32_t blk = 0;
-  while (__any(ctr < 256)) {
-    uint32_t H[4 * XOF90_BLOCKS];
-#pragma unroll 1
-    for (int b = 0; b < XOF90_BLOCKS; b++) {
-      uint32_t o[4];
-      aes256ctr_block(L, rk, cx, blk + b, o);
-      // H[4b..4b+3] = o, with a compile-time destination (b is a run-time loop index)
+  {
+    const long job = (long)blockIdx.x * WG + threadIdx.x;
+    const bool valid = job < njobs;  // idle lanes carry ctr = 256
+    const int jc = valid ? (int)job : njobs - 1;
+    const int inst = jc / P::NMAT, e = jc % P::NMAT;
+    const int i = e / P::K, j = e % P::K;
+    const uint32_t x = transposed ? i : j, y = transposed ? j : i;
+
+    u64p key[4];
+    uint32_t rk[60];
+    ld32B(rho + (size_t)inst * rho_stride, key);
+    aes256_expand(L, key, rk);
+    const AesCtr cx = aes256ctr_init(L, rk, x | y << 8);
+
+    int ctr = valid ? 0 : 256;
+    // one step: parse 48 bytes of keystream into the lane's staging row, move what it holds to the polynomial
+    auto step = [&](const uint32_t (&b0)[4], const uint32_t (&b1)[4], const uint32_t (&b2)[4]) {
+      const uint32_t H[4 * XOF90_BLOCKS] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+      if constexpr (ABLATE == 2) {
 #pragma unroll
-      for (int bb = 0; bb < XOF90_BLOCKS; bb++)
-        if (bb == b) { H[4 * bb] = o[0]; H[4 * bb + 1] = o[1]; H[4 * bb + 2] = o[2]; H[4 * bb + 3] = o[3]; }
+        for (int w = 0; w < 4 * XOF90_BLOCKS; w++) asm volatile("" ::"v"(H[w]));
+        ctr += 24;   // eleven steps, the usual number
+        return;
+      }
+      const uint32_t w0 = row_addr + 2u * (ctr & 1);
+      uint32_t waddr = w0;
+      parse_range<0, XOF90_GROUPS, 4 * XOF90_BLOCKS>(H, waddr);
+      const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
+      if constexpr (ABLATE == 1 || ABLATE == 4) ctr = c1;
+      else ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
+    };
+    // The keystream is produced two blocks at a time (aes256ctr_blocks: the look-ups of one block beside the
+    // logic of the other) and consumed three at a time, so two steps share three pairs; a wavefront that
+    // is done after the first of them has computed one block too many.
+    uint32_t blk = 0;
+    while (AES_NB == 1) {
+      {
+        uint32_t A[3][4];
+#pragma unroll 1
+        for (int b = 0; b < 3; b++) {
+          uint32_t o[4];
+          if constexpr (ABLATE == 3 || ABLATE == 4) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) o[w] = (rk[8 + w] ^ (blk + b)) * 2654435761u;
+          } else {
+            aes256ctr_block(L, rk, cx, blk + b, o);
+          }
+#pragma unroll
+          for (int bb = 0; bb < 3; bb++)
+            if (bb == b) { A[bb][0] = o[0]; A[bb][1] = o[1]; A[bb][2] = o[2]; A[bb][3] = o[3]; }
+        }
+        step(A[0], A[1], A[2]);
+      }
+      if (!__any(ctr < 256)) break;
+      blk += 3;
     }
-    blk += XOF90_BLOCKS;
-    const uint32_t w0 = row_addr + 2u * (ctr & 1);
-    uint32_t waddr = w0;
-    parse_range<0, XOF90_GROUPS, 4 * XOF90_BLOCKS>(H, waddr);
-    const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
-    ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
+    while (AES_NB == 2) {
+      uint32_t A[2][4], B[2][4];
+      aes256ctr_blocks<2>(L, rk, cx, blk, A);
+      aes256ctr_blocks<2>(L, rk, cx, blk + 2, B);
+      step(A[0], A[1], B[0]);
+      if (!__any(ctr < 256)) break;
+      aes256ctr_blocks<2>(L, rk, cx, blk + 4, A);
+      step(B[1], A[0], A[1]);
+      if (!__any(ctr < 256)) break;
+      blk += 6;
+    }
+  }
+}
+
+// nblk keystream blocks from block number `first` on, of n streams: key i, nonce = (nonces[i] as two
+// bytes, ten zero bytes), as both callers above build it.    ref/aes256ctr.c:530-586
+template <int WG>
+__global__ void __launch_bounds__(WG) k_st_aes256ctr(int n, const uint8_t* __restrict__ keys, const uint16_t* __restrict__ nonces,
+                                                     uint32_t first, int nblk, uint8_t* __restrict__ out) {
+  KY_AES_TABLE(tab);
+  aes_table_init(tab);
+  const AesLds L = aes_lds(tab);
+  const long i = (long)blockIdx.x * WG + threadIdx.x;
+  if (i >= n) return;
+  u64p key[4];
+  uint32_t rk[60];
+  ld32B(keys + (size_t)i * 32, key);
+  aes256_expand(L, key, rk);
+  const AesCtr cx = aes256ctr_init(L, rk, nonces[i]);
+  uint4* o4 = reinterpret_cast<uint4*>(out + (size_t)i * nblk * 16);
+  int b = 0;
+#pragma unroll 1
+  for (; b + 2 <= nblk; b += 2) {
+    uint32_t o[2][4];
+    aes256ctr_blocks<2>(L, rk, cx, first + (uint32_t)b, o);
+    o4[b] = make_uint4(o[0][0], o[0][1], o[0][2], o[0][3]);
+    o4[b + 1] = make_uint4(o[1][0], o[1][1], o[1][2], o[1][3]);
+  }
+  if (b < nblk) {
+    uint32_t o[4];
+    aes256ctr_block(L, rk, cx, first + (uint32_t)b, o);
+    o4[b] = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 

@@ -160,6 +160,30 @@ struct Layout {
 
 // SHAKE128 matrix expansion: the main pass gives every entry three blocks, the
 // tail pass finishes the ~1 % that need more.
+// CUs of the current device (the AES kernels choose their workgroup size by it)
+int device_cus() {
+  static std::atomic<int> cus[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cus[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+// the AES kernels: workgroup size by the amount of work (aes_wg)
+#define AES_LAUNCH_WG(name, st, kern, W, jobs_, cus_, args) \
+  RUN(name, st, kern<P, W><<<blocks(jobs_, W), W, 0, st>>> args)
+#define AES_LAUNCH(name, st, kern, jobs, args)                                                      \
+  do {                                                                                              \
+    const size_t jobs_ = (jobs);                                                                    \
+    const int cus_ = device_cus(), wg_ = aes_wg((long)jobs_, cus_);                                 \
+    if (wg_ == AES_WG) AES_LAUNCH_WG(name, st, kern, AES_WG, jobs_, cus_, args);                    \
+    else if (wg_ == AES_WG_MID) AES_LAUNCH_WG(name, st, kern, AES_WG_MID, jobs_, cus_, args);       \
+    else AES_LAUNCH_WG(name, st, kern, AES_WG_SMALL, jobs_, cus_, args);                            \
+  } while (0)
+
 template <class P>
 int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, uint32_t* tailq,
                   uint32_t tail_cap, hipStream_t st);
@@ -223,7 +247,7 @@ template <class P, bool N90>
 int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, Layout<P>& L, hipStream_t st) {
   const int entries = insts * P::NMAT;
   if constexpr (N90) {
-    RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks((size_t)entries, 256), 256, 0, st>>>(entries, rho, rho_stride, transposed, mat));
+    AES_LAUNCH("k90_sample_matrix", st, k90_sample_matrix, (size_t)entries, (entries, rho, rho_stride, transposed, mat));
     return 0;
   } else {
     return sample_matrix<P>(entries, rho, rho_stride, transposed, mat, L.tailq, L.tail_cap, st);
@@ -248,7 +272,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small));
     if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
     if constexpr (N90) {
-      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * 2 * P::K, 256), 256, 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+      AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * 2 * P::K, (m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     }
@@ -296,7 +320,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     if (!shared)
       if (int rc = expand_matrix<P, N90>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
-      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+      AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
@@ -333,7 +357,7 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if (!shared)
       if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
-      RUN("k90_prf", st, k90_prf<P><<<blocks((size_t)m * (2 * P::K + 1), 256), 256, 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
+      AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     }
@@ -478,7 +502,7 @@ template <class P, bool N90>
 int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed, hipStream_t st) {
   if (n * P::NMAT > 0x7fffffffu) return KYBER_HIP_EINVAL;
   if constexpr (N90) {
-    RUN("k90_sample_matrix", st, k90_sample_matrix<P><<<blocks(n * P::NMAT, 256), 256, 0, st>>>((int)(n * P::NMAT), seeds, 32, transposed, mat));
+    AES_LAUNCH("k90_sample_matrix", st, k90_sample_matrix, n * P::NMAT, ((int)(n * P::NMAT), seeds, 32, transposed, mat));
   } else {
     // no workspace here: a null queue keeps every entry in the main kernel until it is complete
     const size_t entries = n * P::NMAT;
@@ -538,7 +562,7 @@ int getnoise_dev(size_t n, int nnonce, int n_eta1, int16_t* r, const uint8_t* se
   if (int rc = prf.alloc(jobs * P::PRF_STRIDE, st)) return rc;
   if (int rc = copy_rows(small.p, SMALL, seeds, 32, 32, n, st)) return rc;
   if constexpr (N90)
-    RUN("k90_prf", st, k90_prf<P><<<blocks(jobs, 256), 256, 0, st>>>((int)n, nnonce, n_eta1, small.p, 0, prf.p));
+    AES_LAUNCH("k90_prf", st, k90_prf, jobs, ((int)n, nnonce, n_eta1, small.p, 0, prf.p));
   else
     RUN("k_prf", st, k_prf<P><<<blocks(jobs, sponge_wg(jobs)), sponge_wg(jobs), 0, st>>>((int)n, nnonce, n_eta1, small.p, 0, prf.p));
   RUN("k_st_noise", st, launch_st_noise<P>(st, jobs, nnonce, n_eta1, r, prf.p));
@@ -1190,6 +1214,14 @@ int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t* ou
   if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, hash_h_dev, n, of_ct, out, in, st);
+}
+int kyber_batch_aes256ctr_dev(size_t n, uint8_t* out, size_t nblocks, const uint8_t* keys, const uint16_t* nonces, uint32_t first_block,
+                              void* stream) {
+  if (!out || !keys || !nonces || nblocks > (1u << 20) || n > (size_t)INT32_MAX) return KYBER_HIP_EINVAL;
+  if (n == 0 || nblocks == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RUN("k_st_aes256ctr", st, k_st_aes256ctr<AES_WG_SMALL><<<blocks(n, AES_WG_SMALL), AES_WG_SMALL, 0, st>>>((int)n, keys, nonces, first_block, (int)nblocks, out));
+  return 0;
 }
 int kyber_batch_getnoise_dev(int k, int nineties, size_t n, int nnonce, int n_eta1, int16_t* r, const uint8_t* seeds, void* stream) {
   if (!r || !seeds) return KYBER_HIP_EINVAL;

@@ -90,6 +90,7 @@ def library():
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
         "kyber_batch_keccak_f1600_dev": [sz, vp, vp],
         "kyber_batch_hash_h_dev": [ci, ci, sz, ci, u8p, u8p, vp],
+        "kyber_batch_aes256ctr_dev": [sz, u8p, sz, u8p, vp, ctypes.c_uint32, vp],
         "kyber_batch_getnoise_dev": [ci, ci, sz, ci, ci, i16p, u8p, vp],
         "kyber_batch_poly_cbd_dev": [ci, sz, i16p, u8p, vp],
         "kyber_batch_poly_tobytes_dev": [sz, u8p, i16p, vp],
@@ -580,6 +581,18 @@ def keccak_f1600_(states):
     n = states.numel() // 25
     _check(library().kyber_batch_keccak_f1600_dev(n, ctypes.c_void_p(states.data_ptr()), _torch_stream()), "kyber_batch_keccak_f1600_dev")
     return states
+
+
+def aes256ctr(keys, nonces, nblocks, first_block=0):
+    """uint8[n,32] keys, int16[n] nonces (the two leading nonce bytes, little-endian) -> uint8[n, nblocks, 16]:
+    the keystream of the 90s sets' XOF / PRF from block `first_block` on."""
+    import torch
+    n = keys.shape[0]
+    out = torch.empty((n, nblocks, 16), dtype=torch.uint8, device=keys.device)
+    _check(library().kyber_batch_aes256ctr_dev(n, _tptr(out, n * nblocks * 16, "out"), nblocks, _tptr(keys, n * 32, "keys"),
+                                               _tptr(nonces, n * 2, "nonces"), first_block, _torch_stream()),
+           "kyber_batch_aes256ctr_dev")
+    return out
 
 
 def hash_h(k, nineties, data, of_ct):

@@ -167,3 +167,27 @@ def test_hash_h_of_keys_and_ciphertexts_matches_oracle(oracle, k, n90):
             row = np.ascontiguousarray(data[i])
             fn(ctypes.c_void_p(h.ctypes.data), ctypes.c_void_p(row.ctypes.data), size)
             assert np.array_equal(got[i], h), (of_ct, i)
+
+
+@pytest.mark.parametrize("first,nblocks", [(0, 8), (0, 33), (250, 12), (255, 2), (256, 5), (0xFFFFFFF0, 4)])
+def test_aes256ctr_keystream_matches_oracle(oracle, first, nblocks):
+    """The 90s sets' XOF / PRF keystream on its own, also past block 255, where the folded first two
+    rounds of the counter-mode kernels give way to full rounds (a matrix entry needs about 30 blocks,
+    so the KEM tests never get there)."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(first % 1000 + nblocks)
+    for n in (300, 1):
+        keys = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        nonces = rng.integers(0, 1 << 16, n, dtype=np.uint16)
+        keys[0] = 0
+        nonces[0] = 0
+        got = kl.aes256ctr(_dev(keys), torch.from_numpy(nonces.view(np.int16)).cuda(), nblocks, first).cpu().numpy()
+        for i in range(0, n, 7):
+            want = np.empty(nblocks * 16, np.uint8)
+            nonce = np.zeros(12, np.uint8)
+            nonce[0], nonce[1] = nonces[i] & 0xFF, nonces[i] >> 8
+            key = np.ascontiguousarray(keys[i])
+            oracle.lib.ko_aes256ctr(ctypes.c_void_p(want.ctypes.data), want.size, ctypes.c_void_p(key.ctypes.data),
+                                    ctypes.c_void_p(nonce.ctypes.data), first)
+            assert np.array_equal(got[i].reshape(-1), want), (n, i)
