@@ -7,7 +7,7 @@ set -e
 R=$1
 export TMPDIR=/tmp
 timeout -k 10 300 python3 bench.py > gpurun_out/${R}_bench_kyber768.json 2> gpurun_out/${R}_bench_kyber768.err
-for w in kyber512 kyber1024 kyber768-90s; do
+for w in kyber512 kyber1024 kyber512-90s kyber768-90s kyber1024-90s; do
   timeout -k 10 200 python3 bench.py --workload $w --steps 5 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_bench_$w.json 2>/dev/null
 done
 timeout -k 10 200 python3 bench.py --shared-key --steps 5 --no-cpu-baseline > gpurun_out/${R}_bench_kyber768_shared_key.json 2>/dev/null
@@ -15,3 +15,7 @@ timeout -k 10 200 python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_kem --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_prof_kem.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_ntt --output-format csv -- python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun_out/${R}_prof_ntt.log 2>&1
 tools/pmc_all.sh $R
+# HBM traffic of the 90s kernels (AES sampler and PRF)
+export PMC_BENCH_ARGS="--workload kyber768-90s --steps 1 --warmup 1 --batch 524288 --no-cpu-baseline --no-side-measurements"
+tools/pmc_pass.sh ${R}_90s_fetch FETCH_SIZE
+tools/pmc_pass.sh ${R}_90s_write WRITE_SIZE

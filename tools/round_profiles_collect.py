@@ -24,4 +24,8 @@ for tag, name in (("", "kem"), ("_ntt", "ntt")):
     tr = [os.path.join(G, "pmc_%s%s_%s" % (run, tag, c)) for c in ("fetch", "write")]
     with open(os.path.join(P, "%s_pmc_traffic%s.json" % (out, "" if name == "kem" else "_ntt")), "w") as fh:
         subprocess.run([sys.executable, summ, "--traffic-json"] + tr, stdout=fh, check=True)
+tr = [os.path.join(G, "pmc_%s_90s_%s" % (run, c)) for c in ("fetch", "write")]
+if all(os.path.isdir(d) for d in tr):
+    with open(os.path.join(P, "%s_pmc_traffic_90s.json" % out), "w") as fh:
+        subprocess.run([sys.executable, summ, "--traffic-json"] + tr, stdout=fh, check=True)
 print("\n".join(sorted(os.listdir(P))))
