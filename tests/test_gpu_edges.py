@@ -163,3 +163,34 @@ def test_batch_sizes_around_the_workgroup_switch(oracle, k):
         assert np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssb[idx].cpu().numpy(), oss), n
         del pk, sk, ct, ssa, ssb, kc, ec
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_90s_batch_sizes_around_the_aes_workgroup_switches(oracle, k):
+    """The AES kernels of the 90s sets run 256-, 512- or 1024-lane workgroups by the number of
+    jobs per launch against the CU count (aes.h aes_wg: up to 256 and 512 jobs per CU): batch sizes
+    that put the matrix sampler (K*K jobs per instance) and the PRF (2K+1) on either side of both
+    switches, last workgroup ragged.  Strided sample against the oracle, every instance round-trips."""
+    import torch
+    kem = kyber_amd.KyberHip(k, 1)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    g = torch.Generator(device="cuda")
+    g.manual_seed(190 + k)
+    sizes = set()
+    for per_cu in (256, 512):
+        for jobs in (k * k, 2 * k + 1):
+            sizes |= {cus * per_cu // jobs, cus * per_cu // jobs + 1}
+    for n in sorted(sizes):
+        kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+        ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        pk, sk = kem.keypair_dev(kc)
+        ct, ssb = kem.enc_dev(pk, ec)
+        ssa = kem.dec_dev(ct, sk)
+        assert torch.equal(ssa, ssb), n
+        idx = torch.cat([torch.arange(0, n, 997, device="cuda"), torch.arange(n - 70, n, device="cuda")])
+        opk, osk = oracle.keypair(k, kc[idx].cpu().numpy(), 1)
+        oct_, oss = oracle.enc(k, opk, ec[idx].cpu().numpy(), 1)
+        assert np.array_equal(pk[idx].cpu().numpy(), opk) and np.array_equal(sk[idx].cpu().numpy(), osk), n
+        assert np.array_equal(ct[idx].cpu().numpy(), oct_) and np.array_equal(ssb[idx].cpu().numpy(), oss), n
+        del pk, sk, ct, ssa, ssb, kc, ec
+    torch.cuda.empty_cache()
