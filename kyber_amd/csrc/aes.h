@@ -39,9 +39,10 @@ constexpr int AES_TABLE_DW = 256 * 2 * AES_TCOPIES;  // two tables: 64 KiB of LD
 constexpr int AES_WG = 1024, AES_WG_MID = 512, AES_WG_SMALL = 256;
 inline int aes_wg(long jobs, int cus) { return jobs <= (long)cus * AES_WG_SMALL ? AES_WG_SMALL : jobs <= (long)cus * AES_WG_MID ? AES_WG_MID : AES_WG; }
 
-// Keystream blocks a work-item advances together (aes256ctr_blocks).  Pairs are 11 % faster where the AES
-// rounds run alone (tools/microbench/aes_rate), but inside the kernels of the KEM, one block after the
-// other is as fast or faster (tools/lib_ab.sh, -DKY_AES_NB=2: k90_sample_matrix 3.03 against 2.99 ms).
+// Keystream blocks a work-item advances together (aes256ctr_blocks).  Pairs are 2 % faster where the AES
+// rounds run alone (tools/microbench/aes_rate; 11 % before aes_round issued a round's look-ups back to
+// back), but inside the kernels of the KEM one block after the other is as fast or faster
+// (tools/lib_ab.sh, -DKY_AES_NB=2: k90_sample_matrix 3.03 against 2.99 ms).
 #ifndef KY_AES_NB
 #define KY_AES_NB 1
 #endif
@@ -100,8 +101,9 @@ __device__ __forceinline__ uint32_t aes_col(const AesLds& L, uint32_t a, uint32_
 }
 // One middle round of NB blocks: all the addresses, then all the look-ups, then the logic.  Left to
 // itself the compiler issues the look-ups two at a time, each pair behind an s_waitcnt for the one before,
-// so a wavefront never has more than two in flight and sixteen wavefronts cannot keep the LDS pipe
-// busy through its latency; with the 16 NB look-ups of a round issued back to back they can.
+// so a wavefront never has more than two in flight.  Four wavefronts per SIMD fill the LDS pipe either
+// way; the one or two per SIMD of the smaller workgroups (small batches) do not, and gain 7-8 % from
+// the 16 NB look-ups of a round issued back to back (aes_rate; -DKY_AES_UNBATCHED for the other order).
 template <int NB>
 __device__ __forceinline__ void aes_round(const AesLds& L, uint32_t (&s)[NB][4], const uint32_t (&rk)[60], int r) {
 #ifdef KY_AES_UNBATCHED
