@@ -97,6 +97,23 @@ def pmc_traffic(kernel, k, chunk):
     return None, None
 
 
+def pmc_traffic_ntt(batch):
+    """The same for the forward NTT kernel (profiles/rNN_pmc_traffic_ntt.json, recorded at the default
+    batch of 2^20 polynomials per launch)."""
+    import glob
+    if batch != 1 << 20:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_ntt.json")), reverse=True):
+        try:
+            ks = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if name.startswith("ky::k_poly_ntt"):
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def host_threads():
     """Threads for the CPU leg: the CPUs this process may run on, bounded by the
     box's per-job CPU share when the harness exports one (OMP_NUM_THREADS)."""
@@ -232,13 +249,15 @@ def bench_ntt(args):
     assert torch.cuda.is_available()
     res = measure_ntt(args.batch, args.steps, args.warmup)
     fwd = res["poly_ntt"]
+    traffic, traffic_src = pmc_traffic_ntt(args.batch)
     print(json.dumps({
         "metric": "batched NTTs/sec per GPU", "value": fwd["polys_per_s"], "unit": "NTT/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": fwd["ms"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
         "config": {"workload": "forward NTT (poly_ntt) on %d polynomials of Z_3329[X]/(X^256+1), in place in HBM" % args.batch},
         "roofline": {"kernel": "k_poly_ntt", "bound": "hbm", "achieved": fwd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": fwd["hbm_frac"], "traffic": None},
+                     "frac": fwd["hbm_frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes": args.batch * 1024.0},
         "kernels": res}), flush=True)
 
 
