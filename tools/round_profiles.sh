@@ -14,6 +14,7 @@ timeout -k 10 200 python3 bench.py --shared-key --steps 5 --no-cpu-baseline > gp
 timeout -k 10 200 python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun_out/${R}_bench_ntt.json 2>/dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_kem --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_prof_kem.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_ntt --output-format csv -- python3 bench.py --workload ntt --steps 20 --warmup 3 > gpurun_out/${R}_prof_ntt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${R}_prof_kem90s --output-format csv -- python3 bench.py --workload kyber768-90s --steps 10 --warmup 2 --no-cpu-baseline --no-side-measurements > gpurun_out/${R}_prof_kem90s.log 2>&1
 tools/pmc_all.sh $R
 # HBM traffic of the 90s kernels (AES sampler and PRF)
 export PMC_BENCH_ARGS="--workload kyber768-90s --steps 1 --warmup 1 --batch 524288 --no-cpu-baseline --no-side-measurements"
