@@ -233,63 +233,60 @@ __global__ void __launch_bounds__(WG) k90_sample_matrix(int njobs, const uint8_t
   uint32_t* row = stage + threadIdx.x * STAGE90_DW;
   const uint32_t row_addr = lds_addr(row);
   uint32_t* out32 = reinterpret_cast<uint32_t*>(mat);
-  {
-    const long job = (long)blockIdx.x * WG + threadIdx.x;
-    const bool valid = job < njobs;  // idle lanes carry ctr = 256
-    const int jc = valid ? (int)job : njobs - 1;
-    const int inst = jc / P::NMAT, e = jc % P::NMAT;
-    const int i = e / P::K, j = e % P::K;
-    const uint32_t x = transposed ? i : j, y = transposed ? j : i;
+  const long job = (long)blockIdx.x * WG + threadIdx.x;
+  const bool valid = job < njobs;  // idle lanes carry ctr = 256
+  const int jc = valid ? (int)job : njobs - 1;
+  const int inst = jc / P::NMAT, e = jc % P::NMAT;
+  const int i = e / P::K, j = e % P::K;
+  const uint32_t x = transposed ? i : j, y = transposed ? j : i;
 
-    u64p key[4];
-    uint32_t rk[60];
-    ld32B(rho + (size_t)inst * rho_stride, key);
-    aes256_expand(L, key, rk);
-    const AesCtr cx = aes256ctr_init(L, rk, x | y << 8);
+  u64p key[4];
+  uint32_t rk[60];
+  ld32B(rho + (size_t)inst * rho_stride, key);
+  aes256_expand(L, key, rk);
+  const AesCtr cx = aes256ctr_init(L, rk, x | y << 8);
 
-    int ctr = valid ? 0 : 256;
-    // one step: parse 48 bytes of keystream into the lane's staging row, move what it holds to the polynomial
-    auto step = [&](const uint32_t (&b0)[4], const uint32_t (&b1)[4], const uint32_t (&b2)[4]) {
-      const uint32_t H[4 * XOF90_BLOCKS] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
-      if constexpr (ABLATE == 2) {
+  int ctr = valid ? 0 : 256;
+  // one step: parse 48 bytes of keystream into the lane's staging row, move what it holds to the polynomial
+  auto step = [&](const uint32_t (&b0)[4], const uint32_t (&b1)[4], const uint32_t (&b2)[4]) {
+    const uint32_t H[4 * XOF90_BLOCKS] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3]};
+    if constexpr (ABLATE == 2) {
 #pragma unroll
-        for (int w = 0; w < 4 * XOF90_BLOCKS; w++) asm volatile("" ::"v"(H[w]));
-        ctr += 24;   // eleven steps, the usual number
-        return;
-      }
-      const uint32_t w0 = row_addr + 2u * (ctr & 1);
-      uint32_t waddr = w0;
-      parse_range<0, XOF90_GROUPS, 4 * XOF90_BLOCKS>(H, waddr);
-      const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
-      if constexpr (ABLATE == 1 || ABLATE == 4) ctr = c1;
-      else ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
-    };
-    // The keystream is produced two blocks at a time (aes256ctr_blocks: the look-ups of one block beside the
-    // logic of the other) and consumed three at a time, so two steps share three pairs; a wavefront that
-    // is done after the first of them has computed one block too many.
-    uint32_t blk = 0;
-    while (AES_NB == 1) {
-      {
-        uint32_t A[3][4];
-#pragma unroll 1
-        for (int b = 0; b < 3; b++) {
-          uint32_t o[4];
-          if constexpr (ABLATE == 3 || ABLATE == 4) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) o[w] = (rk[8 + w] ^ (blk + b)) * 2654435761u;
-          } else {
-            aes256ctr_block(L, rk, cx, blk + b, o);
-          }
-#pragma unroll
-          for (int bb = 0; bb < 3; bb++)
-            if (bb == b) { A[bb][0] = o[0]; A[bb][1] = o[1]; A[bb][2] = o[2]; A[bb][3] = o[3]; }
-        }
-        step(A[0], A[1], A[2]);
-      }
-      if (!__any(ctr < 256)) break;
-      blk += 3;
+      for (int w = 0; w < 4 * XOF90_BLOCKS; w++) asm volatile("" ::"v"(H[w]));
+      ctr += 24;   // eleven steps, the usual number
+      return;
     }
-    while (AES_NB == 2) {
+    const uint32_t w0 = row_addr + 2u * (ctr & 1);
+    uint32_t waddr = w0;
+    parse_range<0, XOF90_GROUPS, 4 * XOF90_BLOCKS>(H, waddr);
+    const int c0 = ctr, c1 = c0 + (int)((waddr - w0) >> 1);
+    if constexpr (ABLATE == 1 || ABLATE == 4) ctr = c1;
+    else ctr = drain_private<STAGE90_DW>(row, job, c0, c1, out32);
+  };
+  if constexpr (AES_NB == 1) {
+    for (uint32_t blk = 0; __any(ctr < 256); blk += XOF90_BLOCKS) {
+      uint32_t A[XOF90_BLOCKS][4];
+#pragma unroll 1
+      for (int b = 0; b < XOF90_BLOCKS; b++) {
+        uint32_t o[4];
+        if constexpr (ABLATE == 3 || ABLATE == 4) {
+#pragma unroll
+          for (int w = 0; w < 4; w++) o[w] = (rk[8 + w] ^ (blk + b)) * 2654435761u;
+        } else {
+          aes256ctr_block(L, rk, cx, blk + b, o);
+        }
+        // A[b] = o, with a compile-time destination (b is a run-time loop index)
+#pragma unroll
+        for (int bb = 0; bb < XOF90_BLOCKS; bb++)
+          if (bb == b) { A[bb][0] = o[0]; A[bb][1] = o[1]; A[bb][2] = o[2]; A[bb][3] = o[3]; }
+      }
+      step(A[0], A[1], A[2]);
+    }
+  } else if (__any(ctr < 256)) {
+    // -DKY_AES_NB=2: the keystream is produced two blocks at a time (aes256ctr_blocks) and consumed three at a
+    // time, so two steps share three pairs; a wavefront that is done after the first of them has computed
+    // one block too many.
+    for (uint32_t blk = 0;; blk += 6) {
       uint32_t A[2][4], B[2][4];
       aes256ctr_blocks<2>(L, rk, cx, blk, A);
       aes256ctr_blocks<2>(L, rk, cx, blk + 2, B);
@@ -298,7 +295,6 @@ __global__ void __launch_bounds__(WG) k90_sample_matrix(int njobs, const uint8_t
       aes256ctr_blocks<2>(L, rk, cx, blk + 4, A);
       step(B[1], A[0], A[1]);
       if (!__any(ctr < 256)) break;
-      blk += 6;
     }
   }
 }
