@@ -12,9 +12,10 @@ import kyber_amd  # noqa: E402
 from kyber_amd import lib as kl  # noqa: E402
 
 L = kl.library()
-kem = kyber_amd.KyberHip(3)
+N90 = int(len(sys.argv) > 1 and sys.argv[1] == "90s")   # tools/latency.py 90s: Kyber768-90s
+kem = kyber_amd.KyberHip(3, N90)
 p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-for n in (1, 16, 256, 4096):
+for n in (1, 16, 256, 4096, 16384):
     rng = np.random.default_rng(n)
     kc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
     ec = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -22,9 +23,9 @@ for n in (1, 16, 256, 4096):
     ct, ss = kem.enc(pk, ec)
     ss2 = np.empty_like(ss)
     res = {}
-    for name, fn in (("keypair", lambda: L.kyber_batch_keypair(3, 0, n, p(pk), p(sk), p(kc))),
-                     ("enc", lambda: L.kyber_batch_enc(3, 0, n, p(ct), p(ss), p(pk), p(ec))),
-                     ("dec", lambda: L.kyber_batch_dec(3, 0, n, p(ss2), p(ct), p(sk)))):
+    for name, fn in (("keypair", lambda: L.kyber_batch_keypair(3, N90, n, p(pk), p(sk), p(kc))),
+                     ("enc", lambda: L.kyber_batch_enc(3, N90, n, p(ct), p(ss), p(pk), p(ec))),
+                     ("dec", lambda: L.kyber_batch_dec(3, N90, n, p(ss2), p(ct), p(sk)))):
         ts = []
         for _ in range(200):
             t0 = time.perf_counter()
