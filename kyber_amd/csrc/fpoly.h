@@ -29,7 +29,7 @@
 
 namespace ky {
 
-__constant__ const float ZETAF[128] = KY_ZETAS_PLAIN_INIT;
+__constant__ __attribute__((aligned(16))) const float ZETAF[128] = KY_ZETAS_PLAIN_INIT;  // aligned: wpoly.h reads runs of 2 and 4
 
 constexpr float QF = 3329.0f;
 constexpr float QINVF = 1.0f / 3329.0f;
