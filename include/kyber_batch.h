@@ -185,6 +185,21 @@ int kyber_batch_poly_ntt_dev(size_t npoly, int16_t *r, void *stream);
 int kyber_batch_poly_invntt_dev(size_t npoly, int16_t *r, void *stream);
 int kyber_batch_poly_basemul_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
 int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
+/* The same four with CANONICAL output: every coefficient is the representative in [0, q) of what the
+ * reference function leaves in its int16 -- the value its own serializers make of it before any byte
+ * is written (ref/poly.c:118-121, ref/polyvec.c:24-26), so nothing downstream can tell the difference.
+ * These are the fast path (exact-integer fp32 arithmetic, kyber_amd/csrc/wpoly.h); the four above
+ * return the reference's exact representatives (invntt, basemul and mul_fused at about half the rate).
+ *   ntt_canon        = poly_ntt mod q                                  ref/poly.c:244-248, ref/ntt.c:80-95
+ *   invntt_canon     = poly_invntt_tomont mod q (factor 2^16 included) ref/poly.c:259-262, ref/ntt.c:106-126
+ *   basemul_canon    = poly_basemul_montgomery mod q (factor 2^-16)    ref/poly.c:273-280, ref/ntt.c:139-146
+ *   mul_fused_canon  = invntt_tomont(poly_ntt(a) o poly_ntt(b)) mod q = a * b in Z_q[X]/(X^256 + 1)
+ * Inputs: any int16 (values beyond what the reference's int16 arithmetic could take are simply
+ * reduced mod q first). */
+int kyber_batch_poly_ntt_canon_dev(size_t npoly, int16_t *r, void *stream);
+int kyber_batch_poly_invntt_canon_dev(size_t npoly, int16_t *r, void *stream);
+int kyber_batch_poly_basemul_canon_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
+int kyber_batch_poly_mul_fused_canon_dev(size_t npoly, int16_t *r, const int16_t *a, const int16_t *b, void *stream);
 
 /* ---- stage-level device entry points (parity tests of single kernels) ----
  * gen_matrix: mat[i][e][256] int16, e = row*k + col of A (transposed = 0) or

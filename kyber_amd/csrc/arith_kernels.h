@@ -404,63 +404,21 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
 // ------------------------------------------------------------------ standalone polynomial kernels
 // (BASELINE.json config 2: batched NTT / basemul / inverse NTT on dense
 // arrays of int16[256] polynomials; 8 polynomials per 256-thread workgroup)
-// The forward transform runs on the fp32 engine (below).  invntt_tomont and
-// basemul stay on the int16 engine: their outputs are the Montgomery path's
-// own representatives in (-q, q) -- montgomery_reduce returns the member of the
-// residue class nearest to p / 2^16, which depends on the exact integer p, not
-// on its residue -- so only the reference's integer sequence reproduces them.
+// The kernels here are the int16 engine: invntt_tomont, basemul and their fusion with the
+// Montgomery path's own representatives in (-q, q) -- montgomery_reduce returns the member of
+// the residue class nearest to p / 2^16, which depends on the exact integer p, not on its
+// residue, so only the reference's integer sequence reproduces them.  They are the debugging
+// API (stage outputs that compare bit for bit with the reference's intermediates); the fast
+// path of config 2 is the wide fp32 engine in wpoly.h, whose outputs are canonical, and which
+// also runs the forward transform (poly_ntt's Barrett-centred output depends on the residue only).
 //
 // The transform kernels are grid-stride loops: a 32-lane group walks over
 // polynomials pi, pi + stride, ... and issues the 16-byte load of its next
-// polynomial before it transforms the current one.  One launch-sized wave of
-// workgroups doing load -> transform -> store in sequence kept only ~3 MB in
-// flight, a quarter of what HBM latency x bandwidth asks for.
+// polynomial before it transforms the current one.
 __device__ __forceinline__ uint4 ld_poly16(const int16_t* base, long pi, int t) {
   return *reinterpret_cast<const uint4*>(base + pi * 256 + 8 * t);
 }
 __device__ __forceinline__ void st_poly16(int16_t* base, long pi, int t, const int (&c)[8]) { lds_put_contig(base + pi * 256, t, c); }
-
-// Forward transform on the fp32 engine: poly_ntt's output is the Barrett-centred
-// representative (ref/poly.c:244-248, ref/reduce.c:35-42), which depends on the
-// residue only, and fred() of a value this small returns exactly that
-// representative.  Inputs are any int16 the reference's int16 arithmetic can
-// take without overflow; a wavefront that sees a coefficient beyond the
-// engine's entry bound (4095) centres its inputs first.
-// Each pass of the loop takes U polynomials per group: all U loads are issued
-// first, then the polynomials are transformed and stored one after the other,
-// so the waits are counted (vmcnt(U-1), ...) and U-1 loads stay in flight behind
-// each transform.  (A load queue carried around the loop -- q[d] = q[d+1], or a
-// ping-pong pair -- made the compiler wait for everything in flight at the top
-// of each iteration, vmcnt(0): nothing overlapped.)
-template <int U>
-__global__ void __launch_bounds__(256) k_poly_ntt(long npoly, int16_t* __restrict__ r) {
-  __shared__ __attribute__((aligned(16))) float wk[8][256];
-  __shared__ float ztab[128];
-  const Grp w = grp();
-  f_twiddles_to_lds(ztab);
-  const long stride = (long)gridDim.x * 8;
-  const long last = npoly - 1;
-  for (long pi = (long)blockIdx.x * 8 + w.g; pi <= last; pi += U * stride) {
-    uint4 in[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) in[u] = ld_poly16(r, min(pi + u * stride, last), w.t);  // clamped: no load under a branch
-    __builtin_amdgcn_sched_barrier(0);  // every load is issued before the first one is waited for
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const long at = pi + u * stride;
-      float f[8];
-      s16x8_to_f(in[u], f);
-      const float big = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
-                              fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
-      if (__any(big > 4095.0f)) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) f[k] = fred(f[k]);
-      }
-      f_ntt_fwd(wk[w.g], ztab, w.t, f);
-      if (at <= last) *reinterpret_cast<uint4*>(r + at * 256 + 8 * w.t) = f_to_s16x8(f);
-    }
-  }
-}
 
 __global__ void __launch_bounds__(256) k_poly_invntt(long npoly, int16_t* __restrict__ r) {
   __shared__ __attribute__((aligned(16))) int16_t wk[8][256];

@@ -22,6 +22,11 @@ void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r);
 void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r);
 void launch_poly_basemul(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
 void launch_poly_mul_fused(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
+// canonical-output kernels of the wide engine (wpoly.h)
+void launch_poly_ntt_canon(hipStream_t st, size_t npoly, int16_t* r);
+void launch_poly_invntt_canon(hipStream_t st, size_t npoly, int16_t* r);
+void launch_poly_basemul_canon(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
+void launch_poly_mul_fused_canon(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b);
 
 // single-function stages (tests/test_gpu_stages.py); eta / d / k outside the supported sets return false
 bool launch_st_cbd(hipStream_t st, int eta, size_t npoly, int16_t* r, const uint8_t* buf);

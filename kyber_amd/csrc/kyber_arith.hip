@@ -2,6 +2,7 @@
 // arithmetic) kernels and their launchers.  Built with -fno-slp-vectorize, see
 // arith_kernels.h.
 #include "arith_kernels.h"
+#include "wpoly.h"
 #include "arith_launch.h"
 
 namespace ky {
@@ -33,14 +34,27 @@ KY_INSTANTIATE(2)
 KY_INSTANTIATE(3)
 KY_INSTANTIATE(4)
 
-// grid-stride transform kernels: 16 workgroups per CU's worth of blocks, each looping over its share
+// grid-stride kernels of the int16 engine: 16 workgroups per CU's worth of blocks, each looping over its share
 static inline unsigned stride_grid(size_t npoly) {
   const unsigned full = nblocks(npoly, 8), cap = 256 * 16;
   return full < cap ? full : cap;
 }
-// U = 1: tools/microbench/ntt_ablate.hip measured U = 1, 2, 4 within 3 % of each other and of the
-// bare load-convert-store loop (the kernel runs at its access pattern's copy rate); U = 1 keeps 8 waves per SIMD
-void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_ntt<1><<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
+// The forward transform and the canonical-output kernels run on the wide engine (wpoly.h): one
+// launch-sized grid, a wavefront takes 4 U consecutive polynomials.  U and the register bound per
+// kernel from tools/microbench/wpoly_rate.hip (profiles/r03_microbench_wpoly_rate.txt).
+template <int OP, int U, int WAVES = 1>
+static inline void launch_wide(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
+  k_wpoly<OP, U, WAVES><<<nblocks(npoly, 16 * U), 256, 0, st>>>((long)npoly, r, a, b);
+}
+void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r) { launch_wide<W_NTT, 2>(st, npoly, r, r, nullptr); }
+void launch_poly_ntt_canon(hipStream_t st, size_t npoly, int16_t* r) { launch_wide<W_NTT_CANON, 2>(st, npoly, r, r, nullptr); }
+void launch_poly_invntt_canon(hipStream_t st, size_t npoly, int16_t* r) { launch_wide<W_INVNTT_CANON, 2>(st, npoly, r, r, nullptr); }
+void launch_poly_basemul_canon(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
+  launch_wide<W_BASEMUL_CANON, 2>(st, npoly, r, a, b);
+}
+void launch_poly_mul_fused_canon(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
+  launch_wide<W_MUL_CANON, 1, 5>(st, npoly, r, a, b);
+}
 void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r) { k_poly_invntt<<<stride_grid(npoly), 256, 0, st>>>((long)npoly, r); }
 void launch_poly_basemul(hipStream_t st, size_t npoly, int16_t* r, const int16_t* a, const int16_t* b) {
   k_poly_basemul<<<nblocks(npoly, 8), 256, 0, st>>>((long)npoly, r, a, b);

@@ -1291,6 +1291,30 @@ int kyber_batch_poly_mul_fused_dev(size_t npoly, int16_t* r, const int16_t* a, c
   RUN("k_poly_mul_fused", static_cast<hipStream_t>(stream), launch_poly_mul_fused(static_cast<hipStream_t>(stream), npoly, r, a, b));
   return 0;
 }
+int kyber_batch_poly_ntt_canon_dev(size_t npoly, int16_t* r, void* stream) {
+  if (!r) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_wpoly_ntt_canon", static_cast<hipStream_t>(stream), launch_poly_ntt_canon(static_cast<hipStream_t>(stream), npoly, r));
+  return 0;
+}
+int kyber_batch_poly_invntt_canon_dev(size_t npoly, int16_t* r, void* stream) {
+  if (!r) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_wpoly_invntt_canon", static_cast<hipStream_t>(stream), launch_poly_invntt_canon(static_cast<hipStream_t>(stream), npoly, r));
+  return 0;
+}
+int kyber_batch_poly_basemul_canon_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
+  if (!r || !a || !b) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_wpoly_basemul_canon", static_cast<hipStream_t>(stream), launch_poly_basemul_canon(static_cast<hipStream_t>(stream), npoly, r, a, b));
+  return 0;
+}
+int kyber_batch_poly_mul_fused_canon_dev(size_t npoly, int16_t* r, const int16_t* a, const int16_t* b, void* stream) {
+  if (!r || !a || !b) return KYBER_HIP_EINVAL;
+  if (!npoly) return 0;
+  RUN("k_wpoly_mul_fused_canon", static_cast<hipStream_t>(stream), launch_poly_mul_fused_canon(static_cast<hipStream_t>(stream), npoly, r, a, b));
+  return 0;
+}
 
 // ---- one node, several GPUs: contiguous shards, one host thread per device ----
 // Instances share nothing (ref/kem.c:23-127 keep no state), so shard g of G is instances

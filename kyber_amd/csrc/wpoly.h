@@ -11,7 +11,8 @@
 //   * Every lane-dependent twiddle (21 forward, 21 inverse) sits in registers as a (zeta, zeta/q)
 //     pair: nothing is looked up inside a transform, no workgroup-shared table, no workgroup barrier.
 //   * A product by a constant is three FMAs (fmulc), a butterfly five full-rate instructions.
-//   * Outputs are canonical ([0, q)), two coefficients at a time with packed 16-bit min/add.
+//   * Outputs are canonical ([0, q)): the last reduction takes the floor quotient (fred_canon, one
+//     instruction more than the centred form) instead of a fix-up after packing.
 //
 // Replaces (behaviour): ref/ntt.c:80-95 ntt, :106-126 invntt, :139-146 basemul as driven by
 // ref/poly.c:244-280, each followed by the canonicalisation every serializer of the reference
@@ -36,6 +37,18 @@ __device__ __forceinline__ float fmulc(float b, Tw w) {
   const float k = __builtin_fmaf(b, w.zq, RND_MAGIC);
   const float m = __builtin_fmaf(k, -QF, QM);
   return __builtin_fmaf(w.z, b, m);
+}
+// The same two with the result in [0, q): the quotient of x - (q-1)/2, rounded to nearest, is
+// floor(x / q), because (x - 1664) / q is never within 1 / 2q of a half while the rounded 1/q puts
+// it off by |x| * 2.44e-8 < 0.41 / q for |x| < 2^24.  One instruction more than the centred forms and
+// nothing to fix up when the coefficient is packed.
+__device__ __forceinline__ float fred_canon(float x) {
+  const float k = __builtin_fmaf(x - 1664.0f, QINVF, RND_MAGIC);
+  return x + __builtin_fmaf(k, -QF, QM);
+}
+__device__ __forceinline__ float fmulc_canon(float b, float z) {
+  const float k = __builtin_fmaf(__builtin_fmaf(z, b, -1664.0f), QINVF, RND_MAGIC);
+  return __builtin_fmaf(z, b, __builtin_fmaf(k, -QF, QM));
 }
 __device__ __forceinline__ void w_ct(float& a, float& b, Tw w) {  // ref/ntt.c:89-91
   const float t = fmulc(b, w);
@@ -99,6 +112,18 @@ __device__ __forceinline__ void w_get_m(const WLane& L, float (&c)[16]) {
 __device__ __forceinline__ void w_fred16(float (&c)[16]) {
 #pragma unroll
   for (int k = 0; k < 16; k++) c[k] = fred(c[k]);
+}
+// Inputs beyond a kernel's entry bound are centred first.  Rare, and decided per wavefront: the empty
+// asm keeps the compiler from turning the branch into 16 reductions plus 16 selects on every call.
+__device__ __forceinline__ void w_centre_if(bool any_wide, float (&c)[16]) {
+  if (any_wide) {
+    asm volatile("");
+    w_fred16(c);
+  }
+}
+__device__ __forceinline__ void w_fred16_canon(float (&c)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) c[k] = fred_canon(c[k]);
 }
 
 // ---------------------------------------------------------------- twiddles of a lane
@@ -177,12 +202,12 @@ __device__ __forceinline__ void w_ntt_fwd(const WLane& L, const WTwFwd& T, float
 
 // ---------------------------------------------------------------- inverse transform
 // in : c[] in S (NTT domain), |c| <= 1665
-// out: c[] in S, scale * INTT(c) as centred residues |c| <= 1665, where the plain inverse transform
+// out: c[] in S, scale * INTT(c) as canonical residues in [0, q), where the plain inverse transform
 //      carries 128^-1: scale = 1 for a true product, 2^16 for the reference's invntt_tomont
-//      (ref/ntt.c:106-126: 1441 = 2^32 / 128).  fin = scale / 128, gin = fin * zeta[1], as twiddles.
+//      (ref/ntt.c:106-126: 1441 = 2^32 / 128).  fin = scale / 128, gin = fin * zeta[1] (centred).
 // bounds: a sum doubles; a difference that enters a product is kept <= 6660 (11.1 M) by reducing
 // the sums that have doubled twice.
-__device__ __forceinline__ void w_ntt_inv(const WLane& L, const WTwInv& T, float (&c)[16], Tw fin, Tw gin) {
+__device__ __forceinline__ void w_ntt_inv(const WLane& L, const WTwInv& T, float (&c)[16], float fin, float gin) {
 #pragma unroll
   for (int g = 0; g < 4; g++)
 #pragma unroll
@@ -219,8 +244,8 @@ __device__ __forceinline__ void w_ntt_inv(const WLane& L, const WTwInv& T, float
 #pragma unroll
   for (int k = 0; k < 8; k++) {  // last layer with the scaling folded in: both outputs are products
     const float s = c[k] + c[k + 8], d = c[k + 8] - c[k];
-    c[k] = fmulc(s, fin);
-    c[k + 8] = fmulc(d, gin);
+    c[k] = fmulc_canon(s, fin);  // |s|, |d| <= 6660: products <= 11.1 M
+    c[k + 8] = fmulc_canon(d, gin);
   }
 }
 
@@ -268,114 +293,120 @@ __device__ __forceinline__ bool w_any_above(const float (&c)[16], float bound) {
   for (int k = 2; k < 16; k += 2) m = fmaxf(m, fmaxf(fabsf(c[k]), fabsf(c[k + 1])));
   return __any(m > bound);
 }
-// centred residues (|c| <= 1665) -> canonical int16 pairs: v < 0 ? v + q : v is min(v, v + q) on
-// unsigned 16-bit lanes, two coefficients per instruction
-__device__ __forceinline__ uint32_t w_canon_pk(uint32_t w) {
-  uint32_t s, r;
-  const uint32_t qq = (uint32_t)Q | (uint32_t)Q << 16;
-  asm("v_pk_add_u16 %0, %1, %2" : "=v"(s) : "v"(w), "s"(qq));
-  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(s));
-  return r;
-}
-template <bool CANON>
+// integer-valued |c| < 2^15 -> int16, S order
 __device__ __forceinline__ void w_pack(const float (&c)[16], uint4& lo, uint4& hi) {
   float a[8], b[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) { a[k] = c[k]; b[k] = c[k + 8]; }
   lo = f_to_s16x8(a);
   hi = f_to_s16x8(b);
-  if constexpr (CANON) {
-    lo = make_uint4(w_canon_pk(lo.x), w_canon_pk(lo.y), w_canon_pk(lo.z), w_canon_pk(lo.w));
-    hi = make_uint4(w_canon_pk(hi.x), w_canon_pk(hi.y), w_canon_pk(hi.z), w_canon_pk(hi.w));
-  }
 }
 
 // ---------------------------------------------------------------- kernels
-// One launch-sized grid: a wavefront takes four consecutive polynomials, loads them, transforms them,
-// stores them and ends -- workgroups are dispatched in index order, so the chip sweeps the arrays
-// front to back as one moving window (grid-stride loops and per-workgroup runs spread the window and
-// measured 15-20 % less out of HBM, tools/microbench/stream_pattern.hip).  In-place use is safe: a
-// wavefront reads all of its four polynomials before it writes any.
+// One launch-sized grid: a wavefront takes 4 U consecutive polynomials, requests all of them, then
+// transforms and stores them four at a time and ends -- workgroups are dispatched in index order, so
+// the chip sweeps the arrays front to back as one moving window (grid-stride loops and per-workgroup
+// runs spread the window and measured 15-20 % less out of HBM, tools/microbench/stream_pattern.hip).
+// In-place use is safe: a wavefront reads all of its polynomials before it writes any.
 enum WOp { W_NTT = 0, W_NTT_CANON, W_INVNTT_CANON, W_BASEMUL_CANON, W_MUL_CANON };
-constexpr int W_POLYS_PER_WG = 16;
 
 // constants of the final scalings (centred residues mod q)
-constexpr float W_MONT = -1044.0f;      // 2^16 mod q
-constexpr float W_MONT_INV = 169.0f;    // 2^-16 mod q
-constexpr float W_INV_TOMONT = 512.0f;  // 2^16 / 128 mod q: what invntt_tomont leaves on its result (ref/ntt.c:123-125)
-constexpr float W_INV_TOMONT_Z1 = -266.0f;   // 512 * zeta[1] mod q = 512 * -1600
+constexpr float W_MONT_INV = 169.0f;          // 2^-16 mod q
+constexpr float W_INV_TOMONT = 512.0f;        // 2^16 / 128 mod q: what invntt_tomont leaves on its result (ref/ntt.c:123-125)
+constexpr float W_INV_TOMONT_Z1 = -266.0f;    // 512 * zeta[1] mod q = 512 * -1600
 constexpr float W_INV_PLAIN = KY_NINV_PLAIN;  // 128^-1 = -26
 constexpr float W_INV_PLAIN_Z1 = 1652.0f;     // -26 * -1600 mod q
 
 template <int OP>
-__global__ void __launch_bounds__(256) k_wpoly(long npoly, int16_t* r, const int16_t* a, const int16_t* b) {
-  __shared__ __attribute__((aligned(16))) float wk[4][1024];
-  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const WLane L = w_lane(wk[wave]);
-  const long pi = (long)blockIdx.x * W_POLYS_PER_WG + 4 * wave + (lane >> 4);
-  const long pc = pi < npoly ? pi : npoly - 1;  // surplus groups of the last workgroup redo the last polynomial
-  const long off = pc * 256 + 8 * L.l;
-  const uint4 a0 = w_ld16(a + off), a1 = w_ld16(a + off + 128);
-  uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-  if constexpr (OP == W_BASEMUL_CANON || OP == W_MUL_CANON) {
-    b0 = w_ld16(b + off);
-    b1 = w_ld16(b + off + 128);
-  }
+struct WTwiddles {
+  WTwFwd F;
+  __device__ __forceinline__ void load(int l) { w_tw_fwd(F, l); }
+};
+template <>
+struct WTwiddles<W_INVNTT_CANON> {
+  WTwInv I;
+  __device__ __forceinline__ void load(int l) { w_tw_inv(I, l); }
+};
+
+// four polynomials of the wavefront: packed inputs -> packed result
+template <int OP>
+__device__ __forceinline__ void w_op(const WLane& L, const WTwiddles<OP>& T, uint4 a0, uint4 a1, uint4 b0, uint4 b1, uint4& lo, uint4& hi) {
   float c[16];
-  uint4 lo, hi;
   if constexpr (OP == W_NTT || OP == W_NTT_CANON) {
-    WTwFwd T;
-    w_tw_fwd(T, L.l);
     w_unpack(a0, a1, c);
-    if (w_any_above(c, 4095.0f)) w_fred16(c);
-    w_ntt_fwd(L, T, c);
-    w_fred16(c);  // the Barrett-centred representative of ref/poly.c:244-248
-    w_pack<OP == W_NTT_CANON>(c, lo, hi);
+    w_centre_if(w_any_above(c, 4095.0f), c);
+    w_ntt_fwd(L, T.F, c);
+    if constexpr (OP == W_NTT) w_fred16(c);  // the Barrett-centred representative of ref/poly.c:244-248
+    else w_fred16_canon(c);
   } else if constexpr (OP == W_INVNTT_CANON) {
-    WTwInv T;
-    w_tw_inv(T, L.l);
     w_unpack(a0, a1, c);
-    if (w_any_above(c, 1665.0f)) w_fred16(c);
-    w_ntt_inv(L, T, c, mk_tw(W_INV_TOMONT), mk_tw(W_INV_TOMONT_Z1));
-    w_pack<true>(c, lo, hi);
+    w_centre_if(w_any_above(c, 1665.0f), c);
+    w_ntt_inv(L, T.I, c, W_INV_TOMONT, W_INV_TOMONT_Z1);
   } else if constexpr (OP == W_BASEMUL_CANON) {
     // poly_basemul_montgomery carries 2^-16: it goes onto b, which has to be centred anyway
-    WTwFwd T;
-    w_tw_fwd(T, L.l);
     float x[16], y[16];
     w_unpack(a0, a1, x);
     w_unpack(b0, b1, y);
-    if (w_any_above(x, 4095.0f)) w_fred16(x);  // against |y| <= 1665 below: two products <= 13.7 M
-    if (w_any_above(y, 4095.0f)) w_fred16(y);
+    w_centre_if(w_any_above(x, 4095.0f), x);  // against |y| <= 1665 below: two products <= 13.7 M
+    w_centre_if(w_any_above(y, 4095.0f), y);
     const Tw minv = mk_tw(W_MONT_INV);
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = fmulc(y[k], minv);  // 169 * 4095 < 2^24
-    w_basemul(c, x, y, T);
-    w_fred16(c);
-    w_pack<true>(c, lo, hi);
+    w_basemul(c, x, y, T.F);
+    w_fred16_canon(c);
   } else {
     // invntt_tomont(poly_ntt(a) o poly_ntt(b)): the 2^-16 of the product and the 2^16 of the inverse
     // transform cancel, what is left is the plain product of a and b in Z_q[X]/(X^256+1)
-    WTwFwd T;
-    w_tw_fwd(T, L.l);
     float x[16], y[16];
     w_unpack(a0, a1, x);
-    if (w_any_above(x, 4095.0f)) w_fred16(x);
-    w_ntt_fwd(L, T, x);
+    w_centre_if(w_any_above(x, 4095.0f), x);
+    w_ntt_fwd(L, T.F, x);
     w_fred16(x);
     w_unpack(b0, b1, y);
-    if (w_any_above(y, 4095.0f)) w_fred16(y);
-    w_ntt_fwd(L, T, y);  // left at <= 8325
-    w_basemul(c, x, y, T);
+    w_centre_if(w_any_above(y, 4095.0f), y);
+    w_ntt_fwd(L, T.F, y);  // left at <= 8325
+    w_basemul(c, x, y, T.F);
     w_fred16(c);
     WTwInv TI;
     w_tw_inv(TI, L.l);
-    w_ntt_inv(L, TI, c, mk_tw(W_INV_PLAIN), mk_tw(W_INV_PLAIN_Z1));
-    w_pack<true>(c, lo, hi);
+    w_ntt_inv(L, TI, c, W_INV_PLAIN, W_INV_PLAIN_Z1);
   }
-  if (pi < npoly) {
-    w_st16(r + off, lo);
-    w_st16(r + off + 128, hi);
+  w_pack(c, lo, hi);
+}
+
+// U batches of four polynomials per wavefront: 16 U polynomials per 256-lane workgroup
+template <int OP, int U, int WAVES = 1>
+__global__ void __launch_bounds__(256, WAVES) k_wpoly(long npoly, int16_t* r, const int16_t* a, const int16_t* b) {
+  constexpr bool TWO = OP == W_BASEMUL_CANON || OP == W_MUL_CANON;
+  __shared__ __attribute__((aligned(16))) float wk[4][1024];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const WLane L = w_lane(wk[wave]);
+  const long p0 = ((long)blockIdx.x * 4 + wave) * (4 * U) + (lane >> 4);
+  uint4 a0[U], a1[U], b0[U], b1[U];
+  long off[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const long pi = p0 + 4 * u;
+    off[u] = (pi < npoly ? pi : npoly - 1) * 256 + 8 * L.l;  // surplus groups of the last workgroup redo the last polynomial
+    a0[u] = w_ld16(a + off[u]);
+    a1[u] = w_ld16(a + off[u] + 128);
+    if constexpr (TWO) {
+      b0[u] = w_ld16(b + off[u]);
+      b1[u] = w_ld16(b + off[u] + 128);
+    } else {
+      b0[u] = b1[u] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  WTwiddles<OP> T;
+  T.load(L.l);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    uint4 lo, hi;
+    w_op<OP>(L, T, a0[u], a1[u], b0[u], b1[u], lo, hi);
+    if (p0 + 4 * u < npoly) {
+      w_st16(r + off[u], lo);
+      w_st16(r + off[u] + 128, hi);
+    }
   }
 }
 

@@ -102,6 +102,10 @@ def library():
         "kyber_batch_poly_invntt_dev": [sz, i16p, vp],
         "kyber_batch_poly_basemul_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_batch_poly_mul_fused_dev": [sz, i16p, i16p, i16p, vp],
+        "kyber_batch_poly_ntt_canon_dev": [sz, i16p, vp],
+        "kyber_batch_poly_invntt_canon_dev": [sz, i16p, vp],
+        "kyber_batch_poly_basemul_canon_dev": [sz, i16p, i16p, i16p, vp],
+        "kyber_batch_poly_mul_fused_canon_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_hip_set_chunk": [sz],
         "kyber_hip_set_tail_capacity": [sz],
         "kyber_hip_profile_enable": [ci],
@@ -511,6 +515,27 @@ def poly_basemul(r, a, b):
 
 def poly_mul_fused(r, a, b):
     _poly_call("kyber_batch_poly_mul_fused_dev", r, a, b)
+    return r
+
+
+# canonical-output forms (coefficients in [0, q)): the fast path, see include/kyber_batch.h
+def poly_ntt_canon_(r):
+    _poly_call("kyber_batch_poly_ntt_canon_dev", r)
+    return r
+
+
+def poly_invntt_canon_(r):
+    _poly_call("kyber_batch_poly_invntt_canon_dev", r)
+    return r
+
+
+def poly_basemul_canon(r, a, b):
+    _poly_call("kyber_batch_poly_basemul_canon_dev", r, a, b)
+    return r
+
+
+def poly_mul_fused_canon(r, a, b):
+    _poly_call("kyber_batch_poly_mul_fused_canon_dev", r, a, b)
     return r
 
 

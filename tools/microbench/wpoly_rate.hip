@@ -43,14 +43,14 @@ static void m_basemul(long* r, const long* a, const long* b) {
 
 __global__ void __launch_bounds__(256) k_wcopy(long npoly, int16_t* r, const int16_t* a) {
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const long pi = (long)blockIdx.x * W_POLYS_PER_WG + 4 * wave + (lane >> 4);
+  const long pi = (long)blockIdx.x * 16 + 4 * wave + (lane >> 4);
   const long pc = pi < npoly ? pi : npoly - 1;
   const long off = pc * 256 + 8 * (lane & 15);
   const uint4 a0 = w_ld16(a + off), a1 = w_ld16(a + off + 128);
   float c[16];
   w_unpack(a0, a1, c);
   uint4 lo, hi;
-  w_pack<false>(c, lo, hi);
+  w_pack(c, lo, hi);
   if (pi < npoly) { w_st16(r + off, lo); w_st16(r + off + 128, hi); }
 }
 
@@ -71,7 +71,7 @@ float timeit(F&& launch, hipEvent_t a, hipEvent_t b) {
 
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 1 << 20;
-  const unsigned grid = (unsigned)((n + W_POLYS_PER_WG - 1) / W_POLYS_PER_WG);
+  const unsigned grid = (unsigned)((n + 15) / 16), grid2 = (unsigned)((n + 31) / 32);
   int16_t *da, *db, *dr;
   CK(hipMalloc(&da, n * 512)); CK(hipMalloc(&db, n * 512)); CK(hipMalloc(&dr, n * 512));
   std::vector<int16_t> ha(n * 256), hb(n * 256), hr(n * 256);
@@ -104,12 +104,16 @@ int main(int argc, char** argv) {
     bad += wrong;
     return 0;
   };
-  k_wpoly<W_NTT_CANON><<<grid, 256>>>(n, dr, da, nullptr); verify("ntt_canon", 0);
-  k_wpoly<W_INVNTT_CANON><<<grid, 256>>>(n, dr, da, nullptr); verify("invntt_canon", 1);
-  k_wpoly<W_BASEMUL_CANON><<<grid, 256>>>(n, dr, da, db); verify("basemul_canon", 2);
-  k_wpoly<W_MUL_CANON><<<grid, 256>>>(n, dr, da, db); verify("mul_fused_canon", 3);
+  k_wpoly<W_NTT_CANON, 1><<<grid, 256>>>(n, dr, da, nullptr); verify("ntt_canon", 0);
+  k_wpoly<W_INVNTT_CANON, 1><<<grid, 256>>>(n, dr, da, nullptr); verify("invntt_canon", 1);
+  k_wpoly<W_BASEMUL_CANON, 1><<<grid, 256>>>(n, dr, da, db); verify("basemul_canon", 2);
+  k_wpoly<W_MUL_CANON, 1><<<grid, 256>>>(n, dr, da, db); verify("mul_fused_canon", 3);
+  k_wpoly<W_NTT_CANON, 2><<<grid2, 256>>>(n, dr, da, nullptr); verify("ntt_canon U=2", 0);
+  k_wpoly<W_INVNTT_CANON, 2><<<grid2, 256>>>(n, dr, da, nullptr); verify("invntt_canon U=2", 1);
+  k_wpoly<W_BASEMUL_CANON, 2><<<grid2, 256>>>(n, dr, da, db); verify("basemul_canon U=2", 2);
+  k_wpoly<W_MUL_CANON, 2><<<grid2, 256>>>(n, dr, da, db); verify("mul_fused_canon U=2", 3);
   {  // the Barrett-centred forward transform: same residues, representative in [-1664, 1664]
-    k_wpoly<W_NTT><<<grid, 256>>>(n, dr, da, nullptr);
+    k_wpoly<W_NTT, 2><<<grid2, 256>>>(n, dr, da, nullptr);
     CK(hipMemcpy(hr.data(), dr, n * 512, hipMemcpyDeviceToHost));
     int wrong = 0;
     for (long pi : check) {
@@ -130,13 +134,24 @@ int main(int argc, char** argv) {
   };
   row("copy (the walk's own roof)", timeit([&] { k_wcopy<<<grid, 256>>>(n, dr, da); }, a, b), 1024);
   row("copy in place", timeit([&] { k_wcopy<<<grid, 256>>>(n, dr, dr); }, a, b), 1024);
-  row("ntt (centred) in place", timeit([&] { k_wpoly<W_NTT><<<grid, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
-  row("ntt_canon in place", timeit([&] { k_wpoly<W_NTT_CANON><<<grid, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
-  row("invntt_canon in place", timeit([&] { k_wpoly<W_INVNTT_CANON><<<grid, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
-  row("basemul_canon", timeit([&] { k_wpoly<W_BASEMUL_CANON><<<grid, 256>>>(n, dr, da, db); }, a, b), 1536);
-  row("mul_fused_canon", timeit([&] { k_wpoly<W_MUL_CANON><<<grid, 256>>>(n, dr, da, db); }, a, b), 1536);
+#define BOTH(name, OP, A, B, bytes)                                                                          \
+  row(name " U=1", timeit([&] { k_wpoly<OP, 1><<<grid, 256>>>(n, dr, A, B); }, a, b), bytes);                  \
+  row(name " U=2", timeit([&] { k_wpoly<OP, 2><<<grid2, 256>>>(n, dr, A, B); }, a, b), bytes)
+  row("ntt_canon U=1 8 waves", timeit([&] { k_wpoly<W_NTT_CANON, 1, 8><<<grid, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("ntt_canon U=2 6 waves", timeit([&] { k_wpoly<W_NTT_CANON, 2, 6><<<grid2, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("ntt_canon U=3", timeit([&] { k_wpoly<W_NTT_CANON, 3><<<(unsigned)((n + 47) / 48), 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("ntt_canon U=4", timeit([&] { k_wpoly<W_NTT_CANON, 4><<<(unsigned)((n + 63) / 64), 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("invntt_canon U=1 8 waves", timeit([&] { k_wpoly<W_INVNTT_CANON, 1, 8><<<grid, 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("invntt_canon U=4", timeit([&] { k_wpoly<W_INVNTT_CANON, 4><<<(unsigned)((n + 63) / 64), 256>>>(n, dr, dr, nullptr); }, a, b), 1024);
+  row("mul_fused_canon U=1 5 waves", timeit([&] { k_wpoly<W_MUL_CANON, 1, 5><<<grid, 256>>>(n, dr, da, db); }, a, b), 1536);
+  row("mul_fused_canon U=2 4 waves", timeit([&] { k_wpoly<W_MUL_CANON, 2, 4><<<grid2, 256>>>(n, dr, da, db); }, a, b), 1536);
+  BOTH("ntt (centred) in place", W_NTT, dr, nullptr, 1024);
+  BOTH("ntt_canon in place", W_NTT_CANON, dr, nullptr, 1024);
+  BOTH("invntt_canon in place", W_INVNTT_CANON, dr, nullptr, 1024);
+  BOTH("basemul_canon", W_BASEMUL_CANON, da, db, 1536);
+  BOTH("mul_fused_canon", W_MUL_CANON, da, db, 1536);
   const unsigned g2 = 4096;
-  row("round 2: k_poly_ntt<1> in place", timeit([&] { k_poly_ntt<1><<<g2, 256>>>(n, dr); }, a, b), 1024);
+  // (round 2's forward kernel, 32 lanes per polynomial in a grid-stride loop, read 4.7-4.8 G/s here: profiles/r03_microbench_wpoly_rate_v1.txt)
   row("round 2: k_poly_invntt (int16)", timeit([&] { k_poly_invntt<<<g2, 256>>>(n, dr); }, a, b), 1024);
   row("round 2: k_poly_basemul (int16)", timeit([&] { k_poly_basemul<<<(unsigned)((n + 7) / 8), 256>>>(n, dr, da, db); }, a, b), 1536);
   row("round 2: k_poly_mul_fused (int16)", timeit([&] { k_poly_mul_fused<<<g2, 256>>>(n, dr, da, db); }, a, b), 1536);
