@@ -314,18 +314,27 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
     // fence is enough) with the one it was given; the 32 lanes' findings meet in a ballot, whose half
     // for this group is non-zero exactly if some byte differs.
     KY_WSYNC();
-    const uint4* mine = reinterpret_cast<const uint4*>(&ctb[li][0]);
-    const uint4* given = reinterpret_cast<const uint4*>(ct + (size_t)gi * P::CTB);
+    // Everything the comparison needs is derived again from the work-item id, through a copy the
+    // compiler cannot trace back: carried from the top of the kernel, the lane number, the instance
+    // number and the ciphertext offsets stayed live through the row loop and pushed the K = 3 kernel
+    // five registers over the 128 of its occupancy bound (20 bytes of scratch per lane, written and
+    // read once: 344 MB of extra HBM writes per 2^19 instances).
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int t2 = (int)(tid & 31u), l2 = (int)(tid >> 5);
+    const int i2 = (int)blockIdx.x * G_INST + l2, g2 = min(i2, n - 1);
+    const uint4* mine = reinterpret_cast<const uint4*>(&ctb[l2][0]);
+    const uint4* given = reinterpret_cast<const uint4*>(ct + (size_t)g2 * P::CTB);
     uint32_t d = 0;
 #pragma unroll
     for (int o = 0; o < (P::CTB / 16 + 31) / 32; o++) {
-      const int b = min(w.t + 32 * o, P::CTB / 16 - 1);   // the last pass re-reads the last block instead of branching
+      const int b = min(t2 + 32 * o, P::CTB / 16 - 1);   // the last pass re-reads the last block instead of branching
       const uint4 x = mine[b], y = given[b];
       d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
     }
     const unsigned long long differ = __ballot(d != 0);
-    const uint32_t flag = (uint32_t)(differ >> (32 * (threadIdx.x >> 5 & 1))) != 0u;
-    if (w.t == 0 && inst0 + li < n) *reinterpret_cast<uint32_t*>(small + (size_t)(inst0 + li) * SMALL + 96) = flag;
+    const uint32_t flag = (uint32_t)(differ >> (32 * (l2 & 1))) != 0u;
+    if (t2 == 0 && i2 < n) *reinterpret_cast<uint32_t*>(small + (size_t)i2 * SMALL + 96) = flag;
   } else {
     __syncthreads();
     // the workgroup's ciphertexts are one contiguous run of global memory
