@@ -61,57 +61,138 @@ AES_MATRIX_ENTRY_BLOCKS = 32     # ref/indcpa.c:160-162,182: 8 x 64-byte XOF blo
 NTT_LANE_OPS, INVNTT_LANE_OPS, BASEMUL_LANE_OPS = 5400, 9000, 2800
 
 
-def lane_ops_per_encdec(k, n90):
+def lane_ops_per_encdec(k, n90, shared=False):
     """Algorithmic 32-bit lane-ops of one encaps + one decaps (symmetric part only, as SURVEY §8(d) prices it)."""
     if not n90:
-        return WORKLOADS["kyber%d" % (256 * k)][3] * KECCAK_LANE_OPS
+        return perms_per_encdec(k, shared) * KECCAK_LANE_OPS
     pkb, ctb = 384 * k + 32, 32 * ((11 if k == 4 else 10) * k + (5 if k == 4 else 4))
     sha256_blocks = lambda nbytes: (nbytes + 9 + 63) // 64
     prf_blocks = lambda eta: (64 * eta) // 16
     eta1 = 3 if k == 2 else 2
-    enc_core = k * k * AES_MATRIX_ENTRY_BLOCKS + k * prf_blocks(eta1) + (k + 1) * prf_blocks(2)  # gen_matrix + noise
+    enc_core = (0 if shared else k * k * AES_MATRIX_ENTRY_BLOCKS) + k * prf_blocks(eta1) + (k + 1) * prf_blocks(2)  # gen_matrix + noise
     aes = 2 * enc_core                                                   # encaps + decaps' re-encryption
-    s256 = sha256_blocks(32) + sha256_blocks(pkb) + 2 * (sha256_blocks(ctb) + sha256_blocks(64))  # H(m0), H(pk), 2 x (H(ct), KDF)
+    s256 = sha256_blocks(32) + (0 if shared else sha256_blocks(pkb)) + 2 * (sha256_blocks(ctb) + sha256_blocks(64))  # H(m0), H(pk), 2 x (H(ct), KDF)
     s512 = 2                                                             # G in encaps and decaps
     return aes * AES_BLOCK_LANE_OPS + s256 * SHA256_BLOCK_LANE_OPS + s512 * SHA512_BLOCK_LANE_OPS
 
 
-def pmc_traffic(kernel, k, chunk):
+def perms_per_encdec(k, shared=False):
+    """Keccak-f per encaps + decaps.  shared: one key pair for the whole batch, so the
+    matrix expansion and H(pk) are done once per call and drop out per instance."""
+    pkb, ctb = 384 * k + 32, 32 * ((11 if k == 4 else 10) * k + (5 if k == 4 else 4))
+    h = lambda nbytes: nbytes // 136 + 1
+    prf = (2 if k == 2 else 1) * k + (k + 1)          # eta1 = 3 needs two blocks per polynomial (Kyber512)
+    enc = 1 + 1 + prf + h(ctb) + 1                    # H(m0), G, noise, H(ct), KDF
+    dec = 1 + prf + h(ctb) + 1                        # G, noise of the re-encryption, H(ct), KDF
+    if not shared:
+        enc += h(pkb) + 3 * k * k
+        dec += 3 * k * k
+    return enc + dec
+
+
+def kernel_work(name, k, n90, shared=False):
+    """Algorithmic work of ONE instance in one launch of a pipeline kernel: (32-bit lane-ops, compulsory HBM
+    bytes), by the constants of SURVEY.md §8(d) / DESIGN.md §4, §4c.  None for kernels whose work is not
+    per instance (the sampler's tail pass, the one-off hashes of the shared-key calls)."""
+    pkb, skb = 384 * k + 32, 768 * k + 96
+    ctb = 32 * ((11 if k == 4 else 10) * k + (5 if k == 4 else 4))
+    eta1 = 3 if k == 2 else 2
+    prf_bytes = lambda jobs_eta1, jobs_eta2: jobs_eta1 * 64 * eta1 + jobs_eta2 * 128
+    h = lambda nbytes: nbytes // 136 + 1                                  # SHA3-256 permutations
+    s256 = lambda nbytes: (nbytes + 9 + 63) // 64                          # SHA-256 compressions
+    P, A, S2, S5 = KECCAK_LANE_OPS, AES_BLOCK_LANE_OPS, SHA256_BLOCK_LANE_OPS, SHA512_BLOCK_LANE_OPS
+    mat_bytes = 0 if shared else k * k * 512
+    t = {
+        # SHAKE sets
+        "k_sample_matrix": (k * k * MATRIX_ENTRY_PERMS * P, k * k * 512 + 32),
+        "k_prf": (((2 if k == 2 else 1) * k + (k + 1)) * P, 32 + prf_bytes(k, k + 1)),
+        "k_enc_pre": ((1 + (0 if shared else h(pkb)) + 1) * P, 32 + (0 if shared else pkb) + 96),
+        "k_dec_mid": (1 * P, 64 + 64),
+        "k_post": ((h(ctb) + 1) * P, ctb + 64 + 32),
+        "k_kp_pre": (1 * P, 32 + 64),
+        "k_kp_post": (h(pkb) * P, pkb + 64),
+        # 90s sets
+        "k90_sample_matrix": (k * k * AES_MATRIX_ENTRY_BLOCKS * A, k * k * 512 + 32),
+        "k90_prf": ((k * 4 * eta1 + (k + 1) * 8) * A, 32 + prf_bytes(k, k + 1)),
+        "k90_enc_pre": ((s256(32) + (0 if shared else s256(pkb))) * S2 + S5, 32 + (0 if shared else pkb) + 96),
+        "k90_dec_mid": (S5, 64 + 64),
+        "k90_post": ((s256(ctb) + s256(64)) * S2, ctb + 64 + 32),
+        "k90_kp_pre": (S5, 32 + 64),
+        "k90_kp_post": (s256(pkb) * S2, pkb + 64),
+        # polynomial arithmetic (both families): NTT / base multiplications / inverse NTT per instance
+        "k_enc_arith": (k * NTT_LANE_OPS + k * (k + 1) * BASEMUL_LANE_OPS + (k + 1) * INVNTT_LANE_OPS,
+                        mat_bytes + prf_bytes(k, k + 1) + 384 * k + 32 + ctb),
+        "k_dec_arith": (k * NTT_LANE_OPS + k * BASEMUL_LANE_OPS + INVNTT_LANE_OPS, ctb + 384 * k + 32),
+        "k_kp_arith": (2 * k * NTT_LANE_OPS + k * k * BASEMUL_LANE_OPS, k * k * 512 + prf_bytes(2 * k, 0) + pkb + skb),
+    }
+    t["k_enc_arith_cmp"] = t["k_enc_arith"]
+    if shared and name in ("k_sample_matrix", "k90_sample_matrix"):  # one expansion per call, not per instance
+        return None
+    return t.get(name)
+
+
+def lib_sha256():
+    """identity of the in-tree libkyber_hip.so: the counter files record which build they measured"""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "kyber_amd", "libkyber_hip.so"), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+# pipeline kernel -> the exact instantiation that runs at 2^19 instances per launch, as rocprofv3 names it
+def _pmc_kernel_name(kernel, k):
+    par = "ky::Par<%d>" % k
+    return {
+        "k_sample_matrix": "ky::k_sample_matrix<%s, 512, 0>" % par, "k90_sample_matrix": "ky::k90_sample_matrix<%s, 1024, 0>" % par,
+        "k_prf": "ky::k_prf<%s >" % par, "k90_prf": "ky::k90_prf<%s, 1024>" % par,
+        "k_enc_arith": "ky::k_enc_arith<%s, false>" % par, "k_enc_arith_cmp": "ky::k_enc_arith<%s, true>" % par,
+        "k_dec_arith": "ky::k_dec_arith<%s >" % par, "k_enc_pre": "ky::k_enc_pre<%s >" % par, "k_dec_mid": "ky::k_dec_mid<%s >" % par,
+        "k90_enc_pre": "ky::k90_enc_pre<%s >" % par, "k90_dec_mid": "ky::k90_dec_mid<%s >" % par,
+    }.get(kernel)
+
+
+def _pmc_lookup(pattern, want):
+    """newest profiles/<pattern> that holds kernel `want` -> (bytes per launch, file, stale?)"""
+    import glob
+    sha = lib_sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(path))
+            v = d["kernels"].get(want)
+        except (OSError, ValueError, KeyError):
+            continue
+        if v is not None:
+            return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), d.get("lib_sha256") != sha
+    return None, None, None
+
+
+def pmc_traffic(kernel, k, chunk, n90=0):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass
-    (profiles/rNN_pmc_traffic.json, written by tools/pmc_pass.sh +
+    (profiles/rNN_pmc_traffic[_90s].json, written by tools/pmc_pass.sh +
     tools/pmc_summarize.py --traffic-json: separate FETCH_SIZE / WRITE_SIZE
     passes, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
     Counters cannot be read from inside this process, so the figure is the
-    recorded one for the same launch size, or None."""
-    import glob
-    if chunk != DEFAULT_CHUNK:
+    recorded one for the same launch size and the same build of the library
+    (the file carries the library's sha256), or None."""
+    want = _pmc_kernel_name(kernel, k)
+    if chunk != DEFAULT_CHUNK or want is None:
         return None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        try:
-            ks = json.load(open(path))["kernels"]
-        except (OSError, ValueError, KeyError):
-            continue
-        for name, v in ks.items():
-            if name.startswith("ky::%s<ky::Par<%d>" % (kernel, k)):
-                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+    v, src, stale = _pmc_lookup("r*_pmc_traffic_90s.json" if n90 else "r*_pmc_traffic.json", want)
+    if v is None or stale:
+        return None, (src + " (another build of the library: figure dropped)") if src else None
+    return v, src
 
 
-def pmc_traffic_ntt(batch):
-    """The same for the forward NTT kernel (profiles/rNN_pmc_traffic_ntt.json, recorded at the default
+def pmc_traffic_ntt(batch, kernel="ky::k_wpoly<0, 2, 1>"):
+    """The same for a polynomial kernel (profiles/rNN_pmc_traffic_ntt.json, recorded at the default
     batch of 2^20 polynomials per launch)."""
-    import glob
     if batch != 1 << 20:
         return None, None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_ntt.json")), reverse=True):
-        try:
-            ks = json.load(open(path))["kernels"]
-        except (OSError, ValueError, KeyError):
-            continue
-        for name, v in ks.items():
-            if name.startswith("ky::k_poly_ntt") or name.startswith("void ky::k_wpoly<0") or name.startswith("ky::k_wpoly<0"):
-                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+    v, src, stale = _pmc_lookup("r*_pmc_traffic_ntt.json", kernel)
+    if v is None or stale:
+        return None, (src + " (another build of the library: figure dropped)") if src else None
+    return v, src
 
 
 def host_threads():
@@ -221,20 +302,33 @@ def measure_ntt(n, steps, warmup):
     r = torch.empty_like(a)
     res = {}
 
+    todo = []
+
     def timed(name, fn, nbytes, lane_ops):
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()  # the kernels are launched on torch's current stream (kyber_amd.lib._torch_stream)
-        for _ in range(steps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / steps
-        res[name] = {"ms": ms, "polys_per_s": n / (ms * 1e-3), "GBps": n * nbytes / (ms * 1e-3) * 1e-9,
-                     "hbm_frac": n * nbytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
-                     "valu_frac": n * lane_ops / (ms * 1e-3) * 1e-12 / VALU_PEAK_TLOPS}
+        todo.append((name, fn, nbytes, lane_ops))
+
+    def run_all(rounds=3):
+        """every kernel `steps` launches back to back per round, `rounds` rounds interleaved over the kernels
+        (the clock a kernel sees depends on what ran before it); the median round is reported"""
+        ms = {name: [] for name, *_ in todo}
+        for name, fn, _, _ in todo:
+            for _ in range(warmup):
+                fn()
+        for _ in range(rounds):
+            for name, fn, _, _ in todo:
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()  # the kernels are launched on torch's current stream (kyber_amd.lib._torch_stream)
+                for _ in range(steps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms[name].append(e0.elapsed_time(e1) / steps)
+        for name, _, nbytes, lane_ops in todo:
+            t = sorted(ms[name])[len(ms[name]) // 2]
+            res[name] = {"ms": t, "polys_per_s": n / (t * 1e-3), "GBps": n * nbytes / (t * 1e-3) * 1e-9,
+                         "hbm_frac": n * nbytes / (t * 1e-3) * 1e-9 / HBM_PEAK_GBS,
+                         "valu_frac": n * lane_ops / (t * 1e-3) * 1e-12 / VALU_PEAK_TLOPS}
 
     work = a.clone()
     # the fast path: canonical outputs, wide fp32 engine (kyber_amd/csrc/wpoly.h)
@@ -244,10 +338,11 @@ def measure_ntt(n, steps, warmup):
     timed("poly_basemul_canon", lambda: kl.poly_basemul_canon(r, a, b), 1536, BASEMUL_LANE_OPS)
     timed("poly_mul_fused_canon", lambda: kl.poly_mul_fused_canon(r, a, b), 1536, 2 * NTT_LANE_OPS + BASEMUL_LANE_OPS + INVNTT_LANE_OPS)
     # the reference-exact representatives (int16 Montgomery engine, the debugging API)
-    work = a.clone()
-    timed("poly_invntt", lambda: kl.poly_invntt_(work), 1024, INVNTT_LANE_OPS)
+    work2 = a.clone()
+    timed("poly_invntt", lambda: kl.poly_invntt_(work2), 1024, INVNTT_LANE_OPS)
     timed("poly_basemul", lambda: kl.poly_basemul(r, a, b), 1536, BASEMUL_LANE_OPS)
     timed("poly_mul_fused", lambda: kl.poly_mul_fused(r, a, b), 1536, 2 * NTT_LANE_OPS + BASEMUL_LANE_OPS + INVNTT_LANE_OPS)
+    run_all()
     # the pipeline of configs[1] in one pass: ntt(a), ntt(b), basemul, invntt (four launches) vs the fused kernel
     wa, wb = a.clone(), b.clone()
 
@@ -465,26 +560,26 @@ def main():
         prof = kl.profile_read()
         kl.profile_enable(False)
         tot = sum(ms for _, ms in prof.values())
+        chunk = min(n, args.chunk or DEFAULT_CHUNK)
         for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
             kernels[name] = {"launches": cnt, "avg_ms": ms / cnt, "share": ms / tot}
-        dom = max(prof.items(), key=lambda kv: kv[1][1])[0]
+            w = kernel_work(name, K, N90, args.shared_key)
+            if w is not None:  # one launch covers `chunk` instances
+                avg_s = ms / cnt * 1e-3
+                kernels[name].update({"valu_frac": chunk * w[0] / avg_s * 1e-12 / VALU_PEAK_TLOPS,
+                                      "hbm_frac": chunk * w[1] / avg_s * 1e-9 / HBM_PEAK_GBS,
+                                      "lane_ops_per_instance": w[0], "bytes_per_instance": w[1]})
+        dom = max(((nm, v) for nm, v in prof.items() if kernel_work(nm, K, N90, args.shared_key)), key=lambda kv: kv[1][1])[0]
         cnt, ms = prof[dom]
         avg_s = ms / cnt * 1e-3
-        chunk = min(n, args.chunk or DEFAULT_CHUNK)
-        if dom == "k_sample_matrix":
+        ops1, bytes1 = kernel_work(dom, K, N90, args.shared_key)
+        if dom in ("k_sample_matrix", "k90_sample_matrix"):
             units, unit_name = chunk * K * K, "matrix entries"
-            ops = units * MATRIX_ENTRY_PERMS * KECCAK_LANE_OPS
-            bytes_ = units * (512 + 32.0 / (K * K))
-        elif dom == "k90_sample_matrix":
-            units, unit_name = chunk * K * K, "matrix entries"
-            ops = units * AES_MATRIX_ENTRY_BLOCKS * AES_BLOCK_LANE_OPS
-            bytes_ = units * (512 + 32.0 / (K * K))
-        else:  # fall back to whole-pipeline accounting for an unexpected dominant kernel
-            units, unit_name = chunk, "instances (whole enc+dec accounting)"
-            ops = chunk * lane_ops_per_encdec(K, N90)
-            bytes_ = chunk * ENCDEC_BYTES
+        else:
+            units, unit_name = chunk, "instances"
+        ops, bytes_ = chunk * ops1, float(chunk * bytes1)
         ach = ops / avg_s * 1e-12
-        traffic, traffic_src = pmc_traffic(dom, K, chunk)
+        traffic, traffic_src = pmc_traffic(dom, K, chunk, N90)
         roof = {
             "kernel": dom, "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s",
             "frac": ach / VALU_PEAK_TLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -509,9 +604,9 @@ def main():
                        "instances_per_gpu": n, "parallelism": "independent instances sharded per GPU, no collective",
                        "dist_backend": backend if dist is not None else None},
             "parity": {"ss_dec_equals_ss_enc": True, "strided_sample_vs_cpu_reference": parity},
-            "pipeline": {"valu_frac": value / world * lane_ops_per_encdec(K, N90) * 1e-12 / VALU_PEAK_TLOPS,
+            "pipeline": {"valu_frac": value / world * lane_ops_per_encdec(K, N90, args.shared_key) * 1e-12 / VALU_PEAK_TLOPS,
                          "hbm_frac": value / world * ENCDEC_BYTES * 1e-9 / HBM_PEAK_GBS,
-                         "lane_ops_per_encdec": lane_ops_per_encdec(K, N90)},
+                         "lane_ops_per_encdec": lane_ops_per_encdec(K, N90, args.shared_key)},
             "roofline": roof, "kernels": kernels,
         }
         if kl is None:

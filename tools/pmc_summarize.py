@@ -9,7 +9,11 @@ reports half of a wide coalesced read stream, so it is doubled; WRITE_SIZE is
 taken as is."""
 import csv, glob, json, sys, collections, re
 as_json = "--traffic-json" in sys.argv
-sys.argv = [a for a in sys.argv if a != "--traffic-json"]
+note = "bench.py --steps 1 --warmup 1 --batch 524288 (one chunk of 2^19 instances per launch)"
+for a in sys.argv:
+    if a.startswith("--note="):
+        note = a[len("--note="):]
+sys.argv = [a for a in sys.argv if a != "--traffic-json" and not a.startswith("--note=")]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for d in sys.argv[1:]:
@@ -27,7 +31,10 @@ if as_json:
         w = agg[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
         out[k] = {"launches": cnt[k]["FETCH_SIZE"], "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
                   "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    print(json.dumps({"note": "bench.py --steps 1 --warmup 1 --batch 524288 (one chunk of 2^19 instances per launch); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "libkyber_hip.so")
+    print(json.dumps({"note": note + "; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+                      "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,  # bench.py drops figures of another build
                       "kernels": out}, indent=1))
     sys.exit(0)
 for k in sorted(agg):

@@ -23,9 +23,11 @@ for tag, name in (("", "kem"), ("_ntt", "ntt")):
         subprocess.run([sys.executable, summ] + sq, stdout=fh, check=True)
     tr = [os.path.join(G, "pmc_%s%s_%s" % (run, tag, c)) for c in ("fetch", "write")]
     with open(os.path.join(P, "%s_pmc_traffic%s.json" % (out, "" if name == "kem" else "_ntt")), "w") as fh:
-        subprocess.run([sys.executable, summ, "--traffic-json"] + tr, stdout=fh, check=True)
+        subprocess.run([sys.executable, summ, "--traffic-json"] + tr +
+                       (["--note=bench.py --workload ntt --steps 3 --warmup 1 (2^20 polynomials per launch)"] if name == "ntt" else []), stdout=fh, check=True)
 tr = [os.path.join(G, "pmc_%s_90s_%s" % (run, c)) for c in ("fetch", "write")]
 if all(os.path.isdir(d) for d in tr):
     with open(os.path.join(P, "%s_pmc_traffic_90s.json" % out), "w") as fh:
-        subprocess.run([sys.executable, summ, "--traffic-json"] + tr, stdout=fh, check=True)
+        subprocess.run([sys.executable, summ, "--traffic-json", "--note=bench.py --workload kyber768-90s --steps 1 --warmup 1 --batch 524288 (2^19 instances per launch)"] + tr,
+                       stdout=fh, check=True)
 print("\n".join(sorted(os.listdir(P))))

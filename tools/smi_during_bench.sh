@@ -3,7 +3,8 @@
 python3 bench.py --steps 600 --warmup 5 --no-cpu-baseline --no-side-measurements > gpurun_out/smi_bench.json 2>/dev/null &
 BP=$!
 for i in $(seq 40); do
-  rocm-smi --showpower --showclocks 2>/dev/null | grep -i "socket\|average\|sclk" | sed 's/.*: //' | tr '\n' ' '
+  printf "t=%s " "$(date +%s.%N | cut -c1-14)"
+  rocm-smi --showpower --showclocks 2>/dev/null | grep -i "power\|sclk\|mclk" | sed 's/^GPU\[[0-9]*\][ \t]*: //' | tr '\n' ';'
   echo
   sleep 0.3
   kill -0 $BP 2>/dev/null || break
