@@ -121,6 +121,29 @@ int kyber_batch_enc_shared_pk_dev(int k, int nineties, size_t n, uint8_t *ct, ui
                                   void *stream);
 int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
 
+/* ---- prepared keys: the one-key calls without their per-call set-up ----
+ * A shared-key call first expands the key's matrix (ref/indcpa.c:270: gen_matrix from rho) and, for
+ * encapsulation, hashes the key (ref/kem.c:64: H(pk)) -- about 0.15 ms of single-key work that a small
+ * batch (n <= 4096) feels on every call.  kyber_hip_prepare_pk / _sk do that once: the handle keeps a
+ * copy of the key, its expanded matrix and H(pk) in device memory of the CURRENT device, and the
+ * *_prepared calls are the shared-key calls minus that work -- same bytes out as
+ * kyber_batch_enc_shared_pk / dec_shared_sk and as n calls of the reference with that key.
+ * The reference has no such state (its functions re-derive everything per call, ref/kem.c:51-127);
+ * this is SURVEY.md 8f-2's "precompute A^ and H(pk) once per pk".
+ * prepare_* return after the handle is complete (they synchronise); a handle is read-only afterwards
+ * and may serve any number of calls, from any thread, on any stream of its device.  _dev: the key is
+ * device memory.  kyber_hip_prepared_free waits for the device, wipes a secret key's copy and frees. */
+typedef struct kyber_hip_prepared kyber_hip_prepared;
+int kyber_hip_prepare_pk(int k, int nineties, const uint8_t *pk, kyber_hip_prepared **out);
+int kyber_hip_prepare_sk(int k, int nineties, const uint8_t *sk, kyber_hip_prepared **out);
+int kyber_hip_prepare_pk_dev(int k, int nineties, const uint8_t *pk, kyber_hip_prepared **out);
+int kyber_hip_prepare_sk_dev(int k, int nineties, const uint8_t *sk, kyber_hip_prepared **out);
+int kyber_hip_prepared_free(kyber_hip_prepared *h);
+int kyber_batch_enc_prepared(const kyber_hip_prepared *pk, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *coins /* n*32 or NULL */);
+int kyber_batch_dec_prepared(const kyber_hip_prepared *sk, size_t n, uint8_t *ss, const uint8_t *ct);
+int kyber_batch_enc_prepared_dev(const kyber_hip_prepared *pk, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *coins, void *stream);
+int kyber_batch_dec_prepared_dev(const kyber_hip_prepared *sk, size_t n, uint8_t *ss, const uint8_t *ct, void *stream);
+
 /* ---- key exchange: ref/kex.c:6-54, ref/kex.h:7-29, batched ----
  * Each call is n independent runs of the reference function of the same name.
  * Message layouts per instance are the reference's (ref/kex.h:7-12):

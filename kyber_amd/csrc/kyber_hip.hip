@@ -290,8 +290,11 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
 // pk_stride == 0: n encapsulations to ONE key -- H(pk) and the matrix are
 // computed once and shared; the bytes written are the same as
 // with n copies of the key.
+// pmat / phpk: the key's expanded matrix and H(pk) from a prepared-key handle (shared calls only);
+// without them a shared call computes both into the workspace first.
 template <class P, bool N90>
-int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st) {
+int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st,
+            const int16_t* pmat = nullptr, const uint8_t* phpk = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
   if (use.rc) return use.rc;
@@ -300,13 +303,13 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
   const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  if (shared) {
+  if (shared && !pmat) {
     if constexpr (N90) RUN("k90_hash_pk", st, k90_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
     else RUN("k_hash_pk", st, k_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
     if (int rc = expand_matrix<P, N90>(1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
   }
-  const uint8_t* hpk = shared ? L.hpk : nullptr;
-  const int16_t* mat = shared ? L.smat : L.mat;
+  const uint8_t* hpk = shared ? (pmat ? phpk : L.hpk) : nullptr;
+  const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
   const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
@@ -338,11 +341,12 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 // sk_stride == 0: n ciphertexts for ONE secret key, matrix expanded once.
 // the kernel sequence of a decapsulation over a workspace that is already laid out
 template <class P, bool N90>
-int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
+int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st,
+            const int16_t* pmat = nullptr) {
   const bool shared = sk_stride == 0;
-  if (shared)
+  if (shared && !pmat)
     if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
-  const int16_t* mat = shared ? L.smat : L.mat;
+  const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
   const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
@@ -374,7 +378,7 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
 }
 
 template <class P, bool N90>
-int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st) {
+int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st, const int16_t* pmat = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
   WsUse use(st);
   if (use.rc) return use.rc;
@@ -382,7 +386,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st);
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat);
 }
 
 // ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
@@ -514,6 +518,81 @@ int gen_matrix_dev(size_t n, int16_t* mat, const uint8_t* seeds, int transposed,
           (k_sample_matrix<P, SPONGE_WG_SMALL><<<blocks(entries, SPONGE_WG_SMALL), SPONGE_WG_SMALL, 0, st>>>((int)entries, seeds, 32, transposed, mat, nullptr, 0u)));
   }
   return 0;
+}
+
+// a device allocation owned by a scope
+struct DevBuf {
+  uint8_t* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), bytes ? bytes : 16));
+    return 0;
+  }
+};
+
+// ---- prepared keys (include/kyber_batch.h: kyber_hip_prepare_pk / _sk) ------------------------
+// What a shared-key call derives from its one key before it touches an instance -- the expanded
+// matrix A^T (ref/indcpa.c:270) and H(pk) (ref/kem.c:64) -- computed once and kept on the device
+// next to a copy of the key.  Immutable once kyber_hip_prepare_* has returned (it synchronises),
+// so any number of calls on any stream of that device may use one handle.
+constexpr uint32_t PREP_MAGIC = 0x4B595052u;  // "KYPR"
+}  // namespace
+struct kyber_hip_prepared {
+  uint32_t magic;
+  int k, n90, dev, is_sk;
+  uint8_t* base;        // one allocation: key bytes | matrix | H(pk)
+  size_t bytes;
+  const uint8_t* key;   // pk (PKB) or sk (SKB)
+  const int16_t* mat;   // A^T, K*K polynomials
+  const uint8_t* hpk;   // 32 bytes (pk handles)
+};
+namespace {
+template <class P, bool N90>
+int prepare_key(const uint8_t* key, int is_sk, int key_on_device, kyber_hip_prepared** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const size_t kb = is_sk ? P::SKB : P::PKB, koff = (kb + 255) & ~(size_t)255, moff = koff + (size_t)P::NMAT * 512;
+  DevBuf buf;
+  if (int rc = buf.alloc(moff + 256)) return rc;
+  HIP_TRY(hipMemcpy(buf.p, key, kb, key_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  hipStream_t st = nullptr;
+  const uint8_t* pk = buf.p + (is_sk ? P::PVB : 0);  // the public key inside a secret key, ref/kem.c:28-29
+  // no workspace here: a null queue keeps every entry in the main kernel until it is complete
+  if (int rc = gen_matrix_dev<P, N90>(1, reinterpret_cast<int16_t*>(buf.p + koff), pk + P::PVB, 1, st)) return rc;
+  if (is_sk) {
+    HIP_TRY(hipMemcpyAsync(buf.p + moff, buf.p + 2 * P::PVB + 32, 32, hipMemcpyDeviceToDevice, st));  // sk carries H(pk), ref/kem.c:30
+  } else {
+    if constexpr (N90) RUN("k90_hash_pk", st, k90_hash_pk<P><<<1, 64, 0, st>>>(pk, buf.p + moff));
+    else RUN("k_hash_pk", st, k_hash_pk<P><<<1, 64, 0, st>>>(pk, buf.p + moff));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  kyber_hip_prepared* h = new kyber_hip_prepared{PREP_MAGIC, P::K, N90 ? 1 : 0, dev, is_sk, buf.p, moff + 256,
+                                                 buf.p, reinterpret_cast<const int16_t*>(buf.p + koff), buf.p + moff};
+  buf.p = nullptr;  // owned by the handle now
+  *out = h;
+  return 0;
+}
+
+// a handle is used on the device it was prepared on, for the operation its key allows
+int prepared_check(const kyber_hip_prepared* h, int want_sk) {
+  if (!h || h->magic != PREP_MAGIC || h->is_sk != want_sk) return KYBER_HIP_EINVAL;
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev != h->dev) {
+    snprintf(g_err, sizeof g_err, "prepared key lives on device %d, current device is %d", h->dev, dev);
+    return KYBER_HIP_EINVAL;
+  }
+  return 0;
+}
+template <class P, bool N90>
+int enc_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* coins, hipStream_t st) {
+  return enc_dev<P, N90>(n, ct, ss, h->key, 0, coins, st, h->mat, h->hpk);
+}
+template <class P, bool N90>
+int dec_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ss, const uint8_t* ct, hipStream_t st) {
+  return dec_dev<P, N90>(n, ss, ct, h->key, 0, st, h->mat);
 }
 
 // ---- key exchange (ref/kex.c:6-54) as batched compositions ----------------------
@@ -648,18 +727,6 @@ int kex_ake_sharedA_dev(size_t n, uint8_t* key, const uint8_t* recv, const uint8
   KX((dec_dev<P, N90>(n, s1.p, ct1.p, ska, P::SKB, st)));
   return kdf_parts<3, N90>(n, s0.p, s1.p, tk, key, st);
 }
-
-// ---- host-pointer wrappers ---------------------------------------------------
-struct DevBuf {
-  uint8_t* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  int alloc(size_t bytes) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), bytes ? bytes : 16));
-    return 0;
-  }
-};
 
 // ---- host-pointer pipelines ------------------------------------------------------
 // A host batch is cut into passes of HOST_PASS instances that flow through three
@@ -881,6 +948,20 @@ int dec_host(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, bool s
                        });
 }
 
+template <class P, bool N90>
+int enc_prepared_host(const kyber_hip_prepared* h, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* coins) {
+  Coins c(coins, n * 32);
+  return host_pipeline(n, {{c.p, 32, false}}, {{ct, P::CTB}, {ss, 32}}, [h](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+    return enc_prepared_dev<P, N90>(h, m, out[0], out[1], in[0], st);
+  });
+}
+template <class P, bool N90>
+int dec_prepared_host(const kyber_hip_prepared* h, size_t n, uint8_t* ss, const uint8_t* ct) {
+  return host_pipeline(n, {{ct, P::CTB, false}}, {{ss, 32}}, [h](size_t m, uint8_t** in, uint8_t** out, hipStream_t st) {
+    return dec_prepared_dev<P, N90>(h, m, out[0], in[0], st);
+  });
+}
+
 // Host-pointer form of a device-pointer routine: stage every argument in device
 // memory, run `f` on the null stream, copy the outputs back.
 struct HostArg {
@@ -1069,6 +1150,56 @@ int kyber_batch_dec_shared_sk(int k, int nineties, size_t n, uint8_t* ss, const 
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
   DISPATCH(k, nineties, dec_host, n, ss, ct, sk, true);
+}
+
+// ---- prepared keys ----
+static int prepare_any(int k, int nineties, const uint8_t* key, int is_sk, int on_device, kyber_hip_prepared** out) {
+  if (!key || !out) return KYBER_HIP_EINVAL;
+  *out = nullptr;
+  DISPATCH(k, nineties, prepare_key, key, is_sk, on_device, out);
+}
+int kyber_hip_prepare_pk(int k, int nineties, const uint8_t* pk, kyber_hip_prepared** out) { return prepare_any(k, nineties, pk, 0, 0, out); }
+int kyber_hip_prepare_sk(int k, int nineties, const uint8_t* sk, kyber_hip_prepared** out) { return prepare_any(k, nineties, sk, 1, 0, out); }
+int kyber_hip_prepare_pk_dev(int k, int nineties, const uint8_t* pk, kyber_hip_prepared** out) { return prepare_any(k, nineties, pk, 0, 1, out); }
+int kyber_hip_prepare_sk_dev(int k, int nineties, const uint8_t* sk, kyber_hip_prepared** out) { return prepare_any(k, nineties, sk, 1, 1, out); }
+int kyber_hip_prepared_free(kyber_hip_prepared* h) {
+  if (!h) return 0;
+  if (h->magic != PREP_MAGIC) return KYBER_HIP_EINVAL;
+  int cur = 0, rc = 0;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != h->dev) HIP_TRY(hipSetDevice(h->dev));
+  hipError_t e = hipDeviceSynchronize();  // no kernel may still read the key
+  if (e == hipSuccess && h->is_sk) e = hipMemset(h->base, 0, h->bytes);  // a secret key was kept here
+  if (e == hipSuccess) e = hipFree(h->base);
+  if (e != hipSuccess) rc = hip_fail(e, "kyber_hip_prepared_free");
+  if (cur != h->dev) (void)hipSetDevice(cur);
+  h->magic = 0;
+  delete h;
+  return rc;
+}
+int kyber_batch_enc_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* coins, void* stream) {
+  if (!ct || !ss || !coins) return KYBER_HIP_EINVAL;
+  if (int rc = prepared_check(h, 0)) return rc;
+  if (n == 0) return 0;
+  DISPATCH(h->k, h->n90, enc_prepared_dev, h, n, ct, ss, coins, static_cast<hipStream_t>(stream));
+}
+int kyber_batch_dec_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ss, const uint8_t* ct, void* stream) {
+  if (!ss || !ct) return KYBER_HIP_EINVAL;
+  if (int rc = prepared_check(h, 1)) return rc;
+  if (n == 0) return 0;
+  DISPATCH(h->k, h->n90, dec_prepared_dev, h, n, ss, ct, static_cast<hipStream_t>(stream));
+}
+int kyber_batch_enc_prepared(const kyber_hip_prepared* h, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* coins) {
+  if (!ct || !ss) return KYBER_HIP_EINVAL;
+  if (int rc = prepared_check(h, 0)) return rc;
+  if (n == 0) return 0;
+  DISPATCH(h->k, h->n90, enc_prepared_host, h, n, ct, ss, coins);
+}
+int kyber_batch_dec_prepared(const kyber_hip_prepared* h, size_t n, uint8_t* ss, const uint8_t* ct) {
+  if (!ss || !ct) return KYBER_HIP_EINVAL;
+  if (int rc = prepared_check(h, 1)) return rc;
+  if (n == 0) return 0;
+  DISPATCH(h->k, h->n90, dec_prepared_host, h, n, ss, ct);
 }
 
 // ---- key exchange ----

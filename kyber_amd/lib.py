@@ -87,6 +87,15 @@ def library():
         "kyber_batch_dec_shared_sk": [ci, ci, sz, u8p, u8p, u8p],
         "kyber_batch_enc_shared_pk_dev": [ci, ci, sz, u8p, u8p, u8p, u8p, vp],
         "kyber_batch_dec_shared_sk_dev": [ci, ci, sz, u8p, u8p, u8p, vp],
+        "kyber_hip_prepare_pk": [ci, ci, u8p, vp],
+        "kyber_hip_prepare_sk": [ci, ci, u8p, vp],
+        "kyber_hip_prepare_pk_dev": [ci, ci, u8p, vp],
+        "kyber_hip_prepare_sk_dev": [ci, ci, u8p, vp],
+        "kyber_hip_prepared_free": [vp],
+        "kyber_batch_enc_prepared": [vp, sz, u8p, u8p, u8p],
+        "kyber_batch_dec_prepared": [vp, sz, u8p, u8p],
+        "kyber_batch_enc_prepared_dev": [vp, sz, u8p, u8p, u8p, vp],
+        "kyber_batch_dec_prepared_dev": [vp, sz, u8p, u8p, vp],
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
         "kyber_batch_keccak_f1600_dev": [sz, vp, vp],
         "kyber_batch_hash_h_dev": [ci, ci, sz, ci, u8p, u8p, vp],
@@ -275,6 +284,14 @@ class KyberHip:
         return ss
 
     # ---- device tensors (torch, uint8, CUDA) ----
+    def prepare_pk(self, pk):
+        """-> PreparedKey for encapsulations to pk (numpy array or CUDA tensor)"""
+        return PreparedKey(self, pk, False)
+
+    def prepare_sk(self, sk):
+        """-> PreparedKey for decapsulations with sk"""
+        return PreparedKey(self, sk, True)
+
     def enc_shared_pk_dev(self, pk, coins, ct=None, ss=None):
         import torch
         n = coins.numel() // 32
@@ -356,6 +373,81 @@ class KyberHip:
                                                    _tptr(seeds, n * 32, "seeds"), int(bool(transposed)),
                                                    _torch_stream()), "kyber_batch_gen_matrix_dev")
         return mat
+
+
+class PreparedKey:
+    """One public or secret key with its expanded matrix and H(pk) resident on the current device
+    (kyber_hip_prepare_pk / _sk): the shared-key calls without their per-call set-up.  Use as a
+    context manager or call close(); a secret key's device copy is wiped on release."""
+
+    def __init__(self, kem, key, secret):
+        self.kem, self.secret = kem, bool(secret)
+        want = kem.sk_bytes if secret else kem.pk_bytes
+        h = ctypes.c_void_p()
+        name = "kyber_hip_prepare_%s" % ("sk" if secret else "pk")
+        if hasattr(key, "is_cuda"):
+            if key.numel() != want:
+                raise ValueError("key: expected %d bytes" % want)
+            rc = getattr(kem.lib, name + "_dev")(kem.k, kem.nineties, _tptr(key, want, "key"), ctypes.byref(h))
+        else:
+            key = _np_u8(np.asarray(key).reshape(-1), (want,), "key")
+            rc = getattr(kem.lib, name)(kem.k, kem.nineties, _ptr(key), ctypes.byref(h))
+        _check(rc, name)
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            _check(self.kem.lib.kyber_hip_prepared_free(h), "kyber_hip_prepared_free")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def enc(self, coins=None, n=None):
+        """n encapsulations to the prepared public key (host arrays); == kem.enc_shared_pk(pk, coins)."""
+        if coins is not None:
+            coins = np.ascontiguousarray(coins, dtype=np.uint8).reshape(-1, 32)
+            n = coins.shape[0]
+        elif n is None:
+            raise ValueError("give coins or n")
+        ct, ss = np.empty((n, self.kem.ct_bytes), np.uint8), np.empty((n, 32), np.uint8)
+        _check(self.kem.lib.kyber_batch_enc_prepared(self._h, n, _ptr(ct), _ptr(ss), _ptr(coins) if coins is not None else None),
+               "kyber_batch_enc_prepared")
+        return ct, ss
+
+    def dec(self, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint8).reshape(-1, self.kem.ct_bytes)
+        ss = np.empty((ct.shape[0], 32), np.uint8)
+        _check(self.kem.lib.kyber_batch_dec_prepared(self._h, ct.shape[0], _ptr(ss), _ptr(ct)), "kyber_batch_dec_prepared")
+        return ss
+
+    def enc_dev(self, coins, ct=None, ss=None):
+        import torch
+        n = coins.numel() // 32
+        ct = torch.empty((n, self.kem.ct_bytes), dtype=torch.uint8, device=coins.device) if ct is None else ct
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=coins.device) if ss is None else ss
+        if n:
+            _check(self.kem.lib.kyber_batch_enc_prepared_dev(self._h, n, _tptr(ct, n * self.kem.ct_bytes, "ct"), _tptr(ss, n * 32, "ss"),
+                                                             _tptr(coins, n * 32, "coins"), _torch_stream()), "kyber_batch_enc_prepared_dev")
+        return ct, ss
+
+    def dec_dev(self, ct, ss=None):
+        import torch
+        n = ct.numel() // self.kem.ct_bytes
+        ss = torch.empty((n, 32), dtype=torch.uint8, device=ct.device) if ss is None else ss
+        if n:
+            _check(self.kem.lib.kyber_batch_dec_prepared_dev(self._h, n, _tptr(ss, n * 32, "ss"), _tptr(ct, n * self.kem.ct_bytes, "ct"),
+                                                             _torch_stream()), "kyber_batch_dec_prepared_dev")
+        return ss
 
 
 class MlKemHip:

@@ -34,3 +34,27 @@ for n in (1, 16, 256, 4096, 16384):
         res[name] = np.median(ts) * 1e6
     assert np.array_equal(ss, ss2)
     print("n=%5d  keypair %7.1f us  enc %7.1f us  dec %7.1f us" % (n, res["keypair"], res["enc"], res["dec"]))
+
+# one key, many operations: the shared-key calls against the same calls through a prepared handle
+# (kyber_hip_prepare_pk / _sk: expanded matrix and H(pk) kept on the device)
+pk1, sk1 = kem.keypair(np.random.default_rng(1).integers(0, 256, (1, 64), dtype=np.uint8))
+with kem.prepare_pk(pk1[0]) as ppk, kem.prepare_sk(sk1[0]) as psk:
+    for n in (1, 256, 4096):
+        ec = np.random.default_rng(n).integers(0, 256, (n, 32), dtype=np.uint8)
+        ct, ss = kem.enc_shared_pk(pk1[0], ec)
+        ct2, ss2, ss3 = np.empty_like(ct), np.empty_like(ss), np.empty_like(ss)
+        res = {}
+        for name, fn in (("enc_shared", lambda: L.kyber_batch_enc_shared_pk(3, N90, n, p(ct2), p(ss2), p(pk1), p(ec))),
+                         ("enc_prepared", lambda: L.kyber_batch_enc_prepared(ppk._h, n, p(ct2), p(ss2), p(ec))),
+                         ("dec_shared", lambda: L.kyber_batch_dec_shared_sk(3, N90, n, p(ss3), p(ct), p(sk1))),
+                         ("dec_prepared", lambda: L.kyber_batch_dec_prepared(psk._h, n, p(ss3), p(ct)))):
+            ts = []
+            for _ in range(200):
+                t0 = time.perf_counter()
+                assert fn() == 0
+                ts.append(time.perf_counter() - t0)
+            res[name] = np.median(ts) * 1e6
+            assert np.array_equal(ct, ct2) and np.array_equal(ss, ss2)
+        assert np.array_equal(ss, ss3)
+        print("n=%5d  one key: enc shared %7.1f us  prepared %7.1f us | dec shared %7.1f us  prepared %7.1f us"
+              % (n, res["enc_shared"], res["enc_prepared"], res["dec_shared"], res["dec_prepared"]))
