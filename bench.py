@@ -414,20 +414,47 @@ def _free_port():
 def launch_ranks(args):
     """--gpus N outside torchrun: start N rank processes of this script.  The
     parent must not initialise the GPU (no torch import here)."""
+    import tempfile
     port = _free_port()
-    procs = []
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        errs.append(tempfile.TemporaryFile())  # every rank's stderr is kept: a rank that dies early says why
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    # Poll instead of blocking on rank 0: when one rank fails (bad device index, missing library) the
+    # others would sit in the rendezvous until its time-out, so they are ended and the failure reported.
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad and failed is None:
+            failed = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
     rcs = [p.wait() for p in procs]
+    if failed is None:
+        failed = next((i for i, rc in enumerate(rcs) if rc != 0), None)
+    out = b"".join(out_chunks)
+    for r, fh in enumerate(errs):
+        fh.seek(0)
+        text = fh.read().decode(errors="replace")
+        fh.close()
+        if text.strip() and (r == 0 or rcs[r] != 0):
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in text.splitlines()))
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with status %d; the other ranks were stopped\n" % (failed, rcs[failed]))
     for line in out.decode().splitlines():  # stdout carries the one JSON line; library chatter (e.g. "[Gloo] Rank 0 ...") goes to stderr
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+        (sys.stdout if line.startswith("{") and failed is None else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return abs(rcs[failed]) if failed is not None else 0
 
 
 def load_engine(args):

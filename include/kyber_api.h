@@ -33,23 +33,51 @@ extern "C" {
 #define pqcrystals_kyber1024_CIPHERTEXTBYTES 1568
 #define pqcrystals_kyber1024_BYTES 32
 
-#define KYBER_API_DECLARE(SET, BASE)                                                   \
-  enum {                                                                               \
-    pqcrystals_##SET##_hip_SECRETKEYBYTES = pqcrystals_##BASE##_SECRETKEYBYTES,        \
-    pqcrystals_##SET##_hip_PUBLICKEYBYTES = pqcrystals_##BASE##_PUBLICKEYBYTES,        \
-    pqcrystals_##SET##_hip_CIPHERTEXTBYTES = pqcrystals_##BASE##_CIPHERTEXTBYTES,      \
-    pqcrystals_##SET##_hip_BYTES = pqcrystals_##BASE##_BYTES                           \
-  };                                                                                   \
+/* Sizes per implementation-tagged name: preprocessor macros, as in the reference, so that
+ * `#if pqcrystals_kyber768_hip_CIPHERTEXTBYTES != 1088` style checks written against ref/api.h
+ * compile against this header too. */
+/* ref/api.h:11-18 */
+#define pqcrystals_kyber512_hip_SECRETKEYBYTES pqcrystals_kyber512_SECRETKEYBYTES
+#define pqcrystals_kyber512_hip_PUBLICKEYBYTES pqcrystals_kyber512_PUBLICKEYBYTES
+#define pqcrystals_kyber512_hip_CIPHERTEXTBYTES pqcrystals_kyber512_CIPHERTEXTBYTES
+#define pqcrystals_kyber512_hip_BYTES pqcrystals_kyber512_BYTES
+/* ref/api.h:20-27 */
+#define pqcrystals_kyber512_90s_hip_SECRETKEYBYTES pqcrystals_kyber512_SECRETKEYBYTES
+#define pqcrystals_kyber512_90s_hip_PUBLICKEYBYTES pqcrystals_kyber512_PUBLICKEYBYTES
+#define pqcrystals_kyber512_90s_hip_CIPHERTEXTBYTES pqcrystals_kyber512_CIPHERTEXTBYTES
+#define pqcrystals_kyber512_90s_hip_BYTES pqcrystals_kyber512_BYTES
+/* ref/api.h:34-41 */
+#define pqcrystals_kyber768_hip_SECRETKEYBYTES pqcrystals_kyber768_SECRETKEYBYTES
+#define pqcrystals_kyber768_hip_PUBLICKEYBYTES pqcrystals_kyber768_PUBLICKEYBYTES
+#define pqcrystals_kyber768_hip_CIPHERTEXTBYTES pqcrystals_kyber768_CIPHERTEXTBYTES
+#define pqcrystals_kyber768_hip_BYTES pqcrystals_kyber768_BYTES
+/* ref/api.h:43-50 */
+#define pqcrystals_kyber768_90s_hip_SECRETKEYBYTES pqcrystals_kyber768_SECRETKEYBYTES
+#define pqcrystals_kyber768_90s_hip_PUBLICKEYBYTES pqcrystals_kyber768_PUBLICKEYBYTES
+#define pqcrystals_kyber768_90s_hip_CIPHERTEXTBYTES pqcrystals_kyber768_CIPHERTEXTBYTES
+#define pqcrystals_kyber768_90s_hip_BYTES pqcrystals_kyber768_BYTES
+/* ref/api.h:57-64 */
+#define pqcrystals_kyber1024_hip_SECRETKEYBYTES pqcrystals_kyber1024_SECRETKEYBYTES
+#define pqcrystals_kyber1024_hip_PUBLICKEYBYTES pqcrystals_kyber1024_PUBLICKEYBYTES
+#define pqcrystals_kyber1024_hip_CIPHERTEXTBYTES pqcrystals_kyber1024_CIPHERTEXTBYTES
+#define pqcrystals_kyber1024_hip_BYTES pqcrystals_kyber1024_BYTES
+/* ref/api.h:66-73 */
+#define pqcrystals_kyber1024_90s_hip_SECRETKEYBYTES pqcrystals_kyber1024_SECRETKEYBYTES
+#define pqcrystals_kyber1024_90s_hip_PUBLICKEYBYTES pqcrystals_kyber1024_PUBLICKEYBYTES
+#define pqcrystals_kyber1024_90s_hip_CIPHERTEXTBYTES pqcrystals_kyber1024_CIPHERTEXTBYTES
+#define pqcrystals_kyber1024_90s_hip_BYTES pqcrystals_kyber1024_BYTES
+
+#define KYBER_API_DECLARE(SET)                                                         \
   int pqcrystals_##SET##_hip_keypair(uint8_t *pk, uint8_t *sk);                        \
   int pqcrystals_##SET##_hip_enc(uint8_t *ct, uint8_t *ss, const uint8_t *pk);         \
   int pqcrystals_##SET##_hip_dec(uint8_t *ss, const uint8_t *ct, const uint8_t *sk);
 
-KYBER_API_DECLARE(kyber512, kyber512)         /* ref/api.h:16-18 */
-KYBER_API_DECLARE(kyber512_90s, kyber512)     /* ref/api.h:25-27 */
-KYBER_API_DECLARE(kyber768, kyber768)         /* ref/api.h:39-41 */
-KYBER_API_DECLARE(kyber768_90s, kyber768)     /* ref/api.h:48-50 */
-KYBER_API_DECLARE(kyber1024, kyber1024)       /* ref/api.h:62-64 */
-KYBER_API_DECLARE(kyber1024_90s, kyber1024)   /* ref/api.h:71-73 */
+KYBER_API_DECLARE(kyber512)
+KYBER_API_DECLARE(kyber512_90s)
+KYBER_API_DECLARE(kyber768)
+KYBER_API_DECLARE(kyber768_90s)
+KYBER_API_DECLARE(kyber1024)
+KYBER_API_DECLARE(kyber1024_90s)
 
 #ifdef __cplusplus
 }

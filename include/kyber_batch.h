@@ -70,10 +70,24 @@ int kyber_batch_dec(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *c
  * independent (the reference's functions share no state, ref/kem.c:23-127), so no
  * device exchanges anything with another; results are byte for byte those of the
  * single-device call.  A device may be named more than once (its shards then
- * queue behind each other).  coins == NULL draws from randombytes() per shard. */
+ * queue behind each other).  coins == NULL: all coins are drawn from randombytes()
+ * by the calling thread, in instance order, before the shards start (an entropy
+ * hook with static state, like ref/test_vectors.c:41, is never entered concurrently). */
 int kyber_batch_keypair_mgpu(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins, int ndev, const int *devices);
 int kyber_batch_enc_mgpu(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, int ndev, const int *devices);
 int kyber_batch_dec_mgpu(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, int ndev, const int *devices);
+/* The same for data that already lives on the GPUs: shard g is n[g] instances in device memory of
+ * HIP device devices[g] (pk[g], sk[g], ... are that device's arrays; coins[g] must not be NULL), queued
+ * on streams[g] (streams == NULL or streams[g] == NULL: that device's default stream).  Nothing is
+ * copied, nothing is waited for: the call enqueues on each device in turn, restores the caller's
+ * current device and returns; the devices run side by side.  Synchronise each stream (or device)
+ * before reading results.  Returns the first error, its shard named in kyber_hip_last_error(). */
+int kyber_batch_keypair_mgpu_dev(int k, int nineties, int ndev, const int *devices, const size_t *n, uint8_t *const *pk,
+                                 uint8_t *const *sk, const uint8_t *const *coins, void *const *streams);
+int kyber_batch_enc_mgpu_dev(int k, int nineties, int ndev, const int *devices, const size_t *n, uint8_t *const *ct, uint8_t *const *ss,
+                             const uint8_t *const *pk, const uint8_t *const *coins, void *const *streams);
+int kyber_batch_dec_mgpu_dev(int k, int nineties, int ndev, const int *devices, const size_t *n, uint8_t *const *ss,
+                             const uint8_t *const *ct, const uint8_t *const *sk, void *const *streams);
 
 /* ---- device-memory batch calls ----
  * Every pointer is device memory on the current HIP device (coins must not be
@@ -99,9 +113,13 @@ int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_
  *     returns KYBER_HIP_EINVAL with a message in kyber_hip_last_error();
  *   - the call makes no hipMalloc / hipFree / allocating library call
  *     (with profiling off, see kyber_hip_profile_enable);
- *   - all calls on one GPU share that one array: two calls whose GPU work
- *     overlaps in time (different streams, no ordering between them) race.
- *     Issue them on one stream, or order the streams yourself. */
+ *   - all calls on one GPU share that one array.  Calls made outside stream capture are
+ *     ordered by the library like the workspace calls (each stream first waits for the
+ *     previous call's last kernel).  Under capture nothing can be ordered for you: a
+ *     captured call, or a graph replay, whose GPU work overlaps another no-allocation call
+ *     on that GPU races on the array -- keep them on one stream or order them yourself;
+ *   - the array keeps the last call's intermediates (m', r', Kbar', PRF bytes) until the
+ *     next call overwrites them or kyber_hip_release() wipes them. */
 #define KYBER_HIP_NOALLOC_MAX_N 4096
 int kyber_batch_dec_dev_noalloc(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);
 size_t kyber_hip_noalloc_max_n(void); /* = KYBER_HIP_NOALLOC_MAX_N of the library that is loaded */
@@ -233,6 +251,10 @@ int kyber_batch_gen_matrix_dev(int k, int nineties, size_t n, int16_t *mat, cons
  * the set: sha3_256, or sha256 for the 90s sets (ref/symmetric.h:27,50), through the FO kernels' absorb loops */
 int kyber_batch_keccak_f1600_dev(size_t n, uint64_t *states, void *stream);
 int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t *out, const uint8_t *in, void *stream);
+/* hash_g: out[i][64] = G(in[i]) with in[i] of inlen = 32 bytes (G(d), ref/indcpa.c:216) or 64 bytes
+ * (G(m || H(pk)), ref/kem.c:65,111): sha3_512, or sha512 for the 90s sets (ref/symmetric.h:28,51;
+ * ref/fips202.c:765-774, ref/sha512.c:77-302), through the device functions of the FO kernels */
+int kyber_batch_hash_g_dev(int nineties, size_t n, size_t inlen, uint8_t *out, const uint8_t *in, void *stream);
 /* aes256ctr: out[i][nblocks][16] = keystream blocks first_block .. first_block + nblocks - 1 of
  * AES-256-CTR(keys[i][32], nonce = nonces[i] as two little-endian bytes followed by ten zero bytes), the
  * XOF and PRF of the 90s sets: aes256ctr_init + aes256ctr_squeezeblocks / aes256ctr_prf, whose callers
@@ -279,7 +301,10 @@ int kyber_hip_set_chunk(size_t instances);
  * finished by the main kernel itself, so any value gives the same output;
  * (size_t)-1 restores the default (1/16 of the entries + 64). */
 int kyber_hip_set_tail_capacity(size_t records);
-/* release the current device's workspace */
+/* Release what the library holds on EVERY device it has run on: workspace, host-path staging
+ * buffers and streams are wiped and freed, the no-allocation scratch array is wiped (it is part of the
+ * code object and stays).  Waits for each such device to be idle first.  The next call rebuilds
+ * what it needs.  Prepared-key handles are the caller's (kyber_hip_prepared_free). */
 int kyber_hip_release(void);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char *kyber_hip_last_error(void);

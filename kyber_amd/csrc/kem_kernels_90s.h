@@ -363,4 +363,35 @@ __global__ void __launch_bounds__(SPONGE_WG, 4) k_st_hash_h(int n, const uint8_t
   }
 }
 
+// G of one 32-byte (NW32 = 1: G(d), ref/indcpa.c:216) or 64-byte (NW32 = 2: G(m || H(pk)), ref/kem.c:65,111)
+// string per work-item: sha3_512 or, for the 90s sets, sha512 (ref/symmetric.h:28,51), through the device
+// functions of the FO kernels
+template <int NW32, bool N90>
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_st_hash_g(int n, const uint8_t* __restrict__ in, uint8_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64p a[4], b[4], lo[4], hi[4];
+  ld32B(in + (size_t)i * 32 * NW32, a);
+  if constexpr (NW32 == 2) ld32B(in + (size_t)i * 64 + 32, b);
+  if constexpr (N90) {
+    sha512_small<NW32>(a, NW32 == 2 ? b : a, lo, hi);
+  } else {
+    u64p A[25];
+    if constexpr (NW32 == 2) {
+      sha3_512_64(A, a, b);
+    } else {
+      keccak_zero(A);
+#pragma unroll
+      for (int w = 0; w < 4; w++) A[w] = a[w];
+      A[4].lo = 0x06;
+      A[8].hi = 0x80000000u;
+      keccak_f1600(A);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) { lo[w] = A[w]; hi[w] = A[4 + w]; }
+  }
+  st32Bv(out + (size_t)i * 64, lo);
+  st32Bv(out + (size_t)i * 64 + 32, hi);
+}
+
 }  // namespace ky

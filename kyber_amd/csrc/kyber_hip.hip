@@ -477,6 +477,16 @@ constexpr size_t NOALLOC_SCRATCH_BYTES =
     max3(Layout<Par<2>>::need(NOALLOC_MAX_N), Layout<Par<3>>::need(NOALLOC_MAX_N), Layout<Par<4>>::need(NOALLOC_MAX_N));
 static __device__ __align__(256) uint8_t scratch[NOALLOC_SCRATCH_BYTES];
 uint8_t* g_scratch_ptr[MAX_DEV] = {};  // device address of `scratch` on each device, guarded by g_dev_mu[dev]
+// Calls outside stream capture are ordered on the device like the workspace calls (WsUse): each
+// first waits for the event recorded behind the previous one.  Under capture nothing is waited for
+// or recorded (an event of the eager world means nothing inside a graph): captured calls and
+// replays that overlap on one GPU race on the array, as the header says.
+struct ScratchOrder {
+  hipEvent_t idle = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+ScratchOrder g_scratch_order[MAX_DEV];
 
 template <class P, bool N90>
 int dec_noalloc(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hipStream_t st) {
@@ -489,17 +499,34 @@ int dec_noalloc(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, hip
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
   std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
-  if (!g_scratch_ptr[dev]) {
+  ScratchOrder& ord = g_scratch_order[dev];
+  if (!g_scratch_ptr[dev]) {  // set-up, once per device: the array's address and the ordering event
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));  // this device's copy (dev is current)
     if (!p) return KYBER_HIP_EHIP;
+    if (!ord.idle) HIP_TRY(hipEventCreateWithFlags(&ord.idle, hipEventDisableTiming));
+    (void)device_cus();  // cached now, so that the AES launches ask the runtime nothing later
     g_scratch_ptr[dev] = static_cast<uint8_t*>(p);
   }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(st, &cap));
+  const bool eager = cap == hipStreamCaptureStatusNone;
+  if (eager && ord.used && ord.last != st) HIP_TRY(hipStreamWaitEvent(st, ord.idle, 0));
   Layout<P> L;
   L.place(g_scratch_ptr[dev], n);
   // what must start at zero (the tail queue's counter) is cleared by sample_matrix
   // on `st`; every other word of the workspace is written before it is read
-  return dec_run<P, N90>(n, n, L, ss, ct, sk, P::SKB, st);
+  const int rc = dec_run<P, N90>(n, n, L, ss, ct, sk, P::SKB, st);
+  if (eager) {
+    if (hipEventRecord(ord.idle, st) == hipSuccess) {
+      ord.last = st;
+      ord.used = true;
+    } else {
+      (void)hipStreamSynchronize(st);  // cannot order the next call on the device: order it on the host
+      ord.used = false;
+    }
+  }
+  return rc;
 }
 
 template <class P, bool N90>
@@ -1346,6 +1373,17 @@ int kyber_batch_hash_h_dev(int k, int nineties, size_t n, int of_ct, uint8_t* ou
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, hash_h_dev, n, of_ct, out, in, st);
 }
+int kyber_batch_hash_g_dev(int nineties, size_t n, size_t inlen, uint8_t* out, const uint8_t* in, void* stream) {
+  if (!out || !in || (inlen != 32 && inlen != 64) || n > 0x7fffffffu || (nineties != 0 && nineties != 1)) return KYBER_HIP_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned wg = sponge_wg(n), nb = blocks(n, wg);
+  if (inlen == 32 && nineties) RUN("k_st_hash_g", st, (k_st_hash_g<1, true><<<nb, wg, 0, st>>>((int)n, in, out)));
+  else if (inlen == 32) RUN("k_st_hash_g", st, (k_st_hash_g<1, false><<<nb, wg, 0, st>>>((int)n, in, out)));
+  else if (nineties) RUN("k_st_hash_g", st, (k_st_hash_g<2, true><<<nb, wg, 0, st>>>((int)n, in, out)));
+  else RUN("k_st_hash_g", st, (k_st_hash_g<2, false><<<nb, wg, 0, st>>>((int)n, in, out)));
+  return 0;
+}
 int kyber_batch_aes256ctr_dev(size_t n, uint8_t* out, size_t nblocks, const uint8_t* keys, const uint16_t* nonces, uint32_t first_block,
                               void* stream) {
   if (!out || !keys || !nonces || nblocks > (1u << 20) || n > (size_t)INT32_MAX) return KYBER_HIP_EINVAL;
@@ -1490,20 +1528,25 @@ int run_sharded(size_t n, int ndev, const int* devices, F&& shard_call) {
 }  // namespace
 }  // extern "C++"
 
+// coins == NULL: every draw from randombytes() happens here, on the calling thread and in instance
+// order, before the shards start -- an entropy hook with static state (the reference's own test
+// doubles: ref/test_vectors.c:41, ref/rng.c:155) must not be entered by ndev threads at once.
 int kyber_batch_keypair_mgpu(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, int ndev,
                              const int* devices) {
   if (!pk || !sk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
   const size_t pkb = kyber_hip_pk_bytes(k), skb = kyber_hip_sk_bytes(k);
+  Coins c(coins, n * 64);
   return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
-    return kyber_batch_keypair(k, nineties, cnt, pk + lo * pkb, sk + lo * skb, coins ? coins + lo * 64 : nullptr);
+    return kyber_batch_keypair(k, nineties, cnt, pk + lo * pkb, sk + lo * skb, c.p + lo * 64);
   });
 }
 int kyber_batch_enc_mgpu(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins, int ndev,
                          const int* devices) {
   if (!ct || !ss || !pk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
   const size_t pkb = kyber_hip_pk_bytes(k), ctb = kyber_hip_ct_bytes(k);
+  Coins c(coins, n * 32);
   return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
-    return kyber_batch_enc(k, nineties, cnt, ct + lo * ctb, ss + lo * 32, pk + lo * pkb, coins ? coins + lo * 32 : nullptr);
+    return kyber_batch_enc(k, nineties, cnt, ct + lo * ctb, ss + lo * 32, pk + lo * pkb, c.p + lo * 32);
   });
 }
 int kyber_batch_dec_mgpu(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, int ndev,
@@ -1512,6 +1555,59 @@ int kyber_batch_dec_mgpu(int k, int nineties, size_t n, uint8_t* ss, const uint8
   const size_t skb = kyber_hip_sk_bytes(k), ctb = kyber_hip_ct_bytes(k);
   return run_sharded(n, ndev, devices, [&](size_t lo, size_t cnt) {
     return kyber_batch_dec(k, nineties, cnt, ss + lo * 32, ct + lo * ctb, sk + lo * skb);
+  });
+}
+
+// Device-resident shards: shard g lives on HIP device devices[g] (its own pk/sk/ct/ss/coins arrays,
+// n[g] instances) and its kernels are queued on streams[g].  Nothing is copied and nothing is waited
+// for: the calling thread visits the devices in turn and enqueues, the devices then run side by side.
+extern "C++" {
+namespace {
+template <class F>
+int each_device(int ndev, const int* devices, F&& call) {
+  if (ndev < 1 || ndev > MAX_DEV || !devices) return KYBER_HIP_EINVAL;
+  int count = 0, home = 0, rc = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  HIP_TRY(hipGetDevice(&home));
+  for (int g = 0; g < ndev; g++)
+    if (devices[g] < 0 || devices[g] >= count) {
+      snprintf(g_err, sizeof g_err, "device %d not present (%d visible)", devices[g], count);
+      return KYBER_HIP_EINVAL;
+    }
+  for (int g = 0; g < ndev && rc == 0; g++) {
+    hipError_t e = hipSetDevice(devices[g]);
+    rc = e == hipSuccess ? call(g) : hip_fail(e, "hipSetDevice");
+    if (rc) {
+      char msg[200];
+      snprintf(msg, sizeof msg, "shard %d: %s", g, g_err);
+      snprintf(g_err, sizeof g_err, "%s", msg);
+    }
+  }
+  (void)hipSetDevice(home);
+  return rc;
+}
+}  // namespace
+}  // extern "C++"
+
+int kyber_batch_keypair_mgpu_dev(int k, int nineties, int ndev, const int* devices, const size_t* n, uint8_t* const* pk,
+                                 uint8_t* const* sk, const uint8_t* const* coins, void* const* streams) {
+  if (!n || !pk || !sk || !coins) return KYBER_HIP_EINVAL;
+  return each_device(ndev, devices, [&](int g) {
+    return kyber_batch_keypair_dev(k, nineties, n[g], pk[g], sk[g], coins[g], streams ? streams[g] : nullptr);
+  });
+}
+int kyber_batch_enc_mgpu_dev(int k, int nineties, int ndev, const int* devices, const size_t* n, uint8_t* const* ct, uint8_t* const* ss,
+                             const uint8_t* const* pk, const uint8_t* const* coins, void* const* streams) {
+  if (!n || !ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
+  return each_device(ndev, devices, [&](int g) {
+    return kyber_batch_enc_dev(k, nineties, n[g], ct[g], ss[g], pk[g], coins[g], streams ? streams[g] : nullptr);
+  });
+}
+int kyber_batch_dec_mgpu_dev(int k, int nineties, int ndev, const int* devices, const size_t* n, uint8_t* const* ss,
+                             const uint8_t* const* ct, const uint8_t* const* sk, void* const* streams) {
+  if (!n || !ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  return each_device(ndev, devices, [&](int g) {
+    return kyber_batch_dec_dev(k, nineties, n[g], ss[g], ct[g], sk[g], streams ? streams[g] : nullptr);
   });
 }
 
@@ -1535,21 +1631,22 @@ int kyber_hip_set_tail_capacity(size_t records) {
   return 0;
 }
 
-int kyber_hip_release(void) {
-  std::lock_guard<std::mutex> hlk(dev_mutex(g_host_mu));  // same order as the host-pointer calls: host lock, then workspace lock
-  std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
+// every device the library holds something on: workspace, host-path staging and streams, and the
+// contents of the no-allocation scratch array (the array itself is part of the code object)
+static int release_device(int dev) {
+  std::lock_guard<std::mutex> hlk(g_host_mu[dev]);  // same order as the host-pointer calls: host lock, then workspace lock
+  std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+  const bool any = g_ws[dev].base || g_host[dev] || g_scratch_ptr[dev];
+  if (!any) return 0;
+  HIP_TRY(hipSetDevice(dev));
+  HIP_TRY(hipDeviceSynchronize());
   if (g_ws[dev].base) {
-    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(g_ws[dev].base, 0, g_ws[dev].bytes));  // sigma, r, m, Kbar, PRF bytes of the last call
     HIP_TRY(hipFree(g_ws[dev].base));
     if (g_ws[dev].idle) (void)hipEventDestroy(g_ws[dev].idle);
     g_ws[dev] = Workspace{};
   }
   if (HostCtx* c = g_host[dev]) {
-    HIP_TRY(hipDeviceSynchronize());
     if (c->staging) {
       HIP_TRY(hipMemset(c->staging, 0, c->cap));  // secret keys and shared secrets were staged here
       HIP_TRY(hipFree(c->staging));
@@ -1557,7 +1654,20 @@ int kyber_hip_release(void) {
     delete c;  // streams and events
     g_host[dev] = nullptr;
   }
+  if (g_scratch_ptr[dev]) {
+    HIP_TRY(hipMemset(g_scratch_ptr[dev], 0, NOALLOC_SCRATCH_BYTES));  // m', r', Kbar', PRF bytes of the last no-allocation call
+    g_scratch_order[dev].used = false;
+  }
   return 0;
+}
+int kyber_hip_release(void) {
+  int home = 0, count = 0, rc = 0;
+  HIP_TRY(hipGetDevice(&home));
+  HIP_TRY(hipGetDeviceCount(&count));
+  for (int dev = 0; dev < count && dev < MAX_DEV; dev++)
+    if (int r = release_device(dev)) rc = rc ? rc : r;
+  (void)hipSetDevice(home);
+  return rc;
 }
 
 const char* kyber_hip_last_error(void) { return g_err; }
@@ -1620,12 +1730,16 @@ __attribute__((weak)) void randombytes(uint8_t* out, size_t outlen) {
     uint8_t coins[64];                                                                                         \
     randombytes(coins, 32);      /* d,  ref/indcpa.c:215 */                                                    \
     randombytes(coins + 32, 32); /* z,  ref/kem.c:32     */                                                    \
-    return kyber_batch_keypair(KK, N90, 1, pk, sk, coins);                                                     \
+    const int rc = kyber_batch_keypair(KK, N90, 1, pk, sk, coins);                                             \
+    explicit_bzero(coins, sizeof coins); /* d and z do not outlive the call on this stack */                   \
+    return rc;                                                                                                 \
   }                                                                                                            \
   int pqcrystals_##NAME##_hip_enc(uint8_t* ct, uint8_t* ss, const uint8_t* pk) {                               \
     uint8_t coins[32];                                                                                         \
     randombytes(coins, 32); /* m0, ref/kem.c:59 */                                                             \
-    return kyber_batch_enc(KK, N90, 1, ct, ss, pk, coins);                                                     \
+    const int rc = kyber_batch_enc(KK, N90, 1, ct, ss, pk, coins);                                             \
+    explicit_bzero(coins, sizeof coins);                                                                       \
+    return rc;                                                                                                 \
   }                                                                                                            \
   int pqcrystals_##NAME##_hip_dec(uint8_t* ss, const uint8_t* ct, const uint8_t* sk) {                         \
     return kyber_batch_dec(KK, N90, 1, ss, ct, sk);                                                            \

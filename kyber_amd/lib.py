@@ -70,6 +70,9 @@ def library():
         "kyber_batch_keypair_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
         "kyber_batch_enc_mgpu": [ci, ci, sz, u8p, u8p, u8p, u8p, ci, vp],
         "kyber_batch_dec_mgpu": [ci, ci, sz, u8p, u8p, u8p, ci, vp],
+        "kyber_batch_keypair_mgpu_dev": [ci, ci, ci, vp, vp, vp, vp, vp, vp],
+        "kyber_batch_enc_mgpu_dev": [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp],
+        "kyber_batch_dec_mgpu_dev": [ci, ci, ci, vp, vp, vp, vp, vp, vp],
         "mlkem_batch_keypair": [ci, sz, u8p, u8p, u8p],
         "mlkem_batch_encaps": [ci, sz, u8p, u8p, u8p, u8p],
         "mlkem_batch_decaps": [ci, sz, u8p, u8p, u8p],
@@ -99,6 +102,7 @@ def library():
         "kyber_batch_gen_matrix_dev": [ci, ci, sz, i16p, u8p, ci, vp],
         "kyber_batch_keccak_f1600_dev": [sz, vp, vp],
         "kyber_batch_hash_h_dev": [ci, ci, sz, ci, u8p, u8p, vp],
+        "kyber_batch_hash_g_dev": [ci, sz, sz, u8p, u8p, vp],
         "kyber_batch_aes256ctr_dev": [sz, u8p, sz, u8p, vp, ctypes.c_uint32, vp],
         "kyber_batch_getnoise_dev": [ci, ci, sz, ci, ci, i16p, u8p, vp],
         "kyber_batch_poly_cbd_dev": [ci, sz, i16p, u8p, vp],
@@ -719,4 +723,14 @@ def hash_h(k, nineties, data, of_ct):
     out = torch.empty((n, 32), dtype=torch.uint8, device=data.device)
     _check(library().kyber_batch_hash_h_dev(k, int(nineties), n, int(bool(of_ct)), _tptr(out, n * 32, "out"),
                                             _tptr(data, data.numel(), "in"), _torch_stream()), "kyber_batch_hash_h_dev")
+    return out
+
+
+def hash_g(nineties, data):
+    """uint8[n, 32 or 64] -> uint8[n,64]: sha3_512 / sha512 as the FO kernels compute it."""
+    import torch
+    n, inlen = data.shape
+    out = torch.empty((n, 64), dtype=torch.uint8, device=data.device)
+    _check(library().kyber_batch_hash_g_dev(int(nineties), n, inlen, _tptr(out, n * 64, "out"), _tptr(data, n * inlen, "in"), _torch_stream()),
+           "kyber_batch_hash_g_dev")
     return out

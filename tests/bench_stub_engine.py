@@ -31,3 +31,11 @@ class StubEngine:
 
 def make(k, nineties):
     return StubEngine(k, nineties)
+
+
+def make_failing_rank1(k, nineties):
+    """rank 1 dies while rank 0 carries on into the barrier: what the launcher must not wait out"""
+    import os
+    if os.environ.get("RANK") == "1":
+        raise SystemExit(7)
+    return StubEngine(k, nineties)

@@ -43,6 +43,21 @@ def test_gpus_2_launches_two_ranks():
     assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
 
 
+def test_failed_rank_ends_the_job_promptly():
+    """one rank exits non-zero: the launcher stops the others instead of sitting out the rendezvous /
+    barrier time-out, prints no JSON line, names the rank and passes its stderr on"""
+    import time
+    env = _env()
+    env["KYBER_BENCH_ENGINE"] = "bench_stub_engine:make_failing_rank1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+           "--device", "cpu", "--no-cpu-baseline"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr.decode())
+    assert time.time() - t0 < 120
+    assert b"{" not in r.stdout and b"rank 1 exited with status 7" in r.stderr
+
+
 def test_one_rank_under_torchrun_and_world_mismatch():
     base = [os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--batch", "8", "--device", "cpu", "--no-cpu-baseline"]
     run = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

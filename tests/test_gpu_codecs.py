@@ -169,6 +169,24 @@ def test_hash_h_of_keys_and_ciphertexts_matches_oracle(oracle, k, n90):
             assert np.array_equal(got[i], h), (of_ct, i)
 
 
+@pytest.mark.parametrize("n90", [0, 1])
+@pytest.mark.parametrize("inlen", [32, 64])
+def test_hash_g_matches_oracle(oracle, n90, inlen):
+    """G = sha3_512 (sha512 for the 90s sets, ref/sha512.c:77-302) on the two input lengths the KEM
+    uses: 32 bytes (G(d), key generation) and 64 bytes (G(m || H(pk)), encapsulation and decapsulation)"""
+    import ctypes
+    n = 1000
+    data = np.random.default_rng(inlen + n90).integers(0, 256, (n, inlen), dtype=np.uint8)
+    data[0], data[1], data[2, -1] = 0x00, 0xFF, 0x80
+    got = kl.hash_g(n90, _dev(data)).cpu().numpy()
+    fn = oracle.lib.ko_sha512 if n90 else oracle.lib.ko_sha3_512
+    for i in range(n):
+        h = np.empty(64, np.uint8)
+        row = np.ascontiguousarray(data[i])
+        fn(ctypes.c_void_p(h.ctypes.data), ctypes.c_void_p(row.ctypes.data), inlen)
+        assert np.array_equal(got[i], h), i
+
+
 @pytest.mark.parametrize("first,nblocks", [(0, 8), (0, 33), (250, 12), (255, 2), (256, 5), (0xFFFFFFF0, 4)])
 def test_aes256ctr_keystream_matches_oracle(oracle, first, nblocks):
     """The 90s sets' XOF / PRF keystream on its own, also past block 255, where the folded first two

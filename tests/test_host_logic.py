@@ -22,7 +22,7 @@ def _declared_symbols():
     for s in re.findall(r"^KYBER_HIP_DECLARE_SET\((\w+)\)", batch, re.M):
         names.update("%s_batch_%s" % (s, op) for op in ("keypair", "enc", "dec"))
     api = open(os.path.join(ROOT, "include", "kyber_api.h")).read()
-    for s in re.findall(r"^KYBER_API_DECLARE\((\w+),", api, re.M):
+    for s in re.findall(r"^KYBER_API_DECLARE\((\w+)\)", api, re.M):
         names.update("pqcrystals_%s_hip_%s" % (s, op) for op in ("keypair", "enc", "dec"))
     names.discard("NAME")
     return {n for n in names if not n.startswith("NAME") and not n.startswith("pqcrystals_##")}
@@ -46,6 +46,20 @@ def test_sizes_match_reference_api_macros():
         assert (lib.kyber_hip_pk_bytes(k), lib.kyber_hip_sk_bytes(k), lib.kyber_hip_ct_bytes(k)) == kyber_amd.sizes(k)
         assert all(s % 16 == 0 for s in kyber_amd.sizes(k))
     assert lib.kyber_hip_pk_bytes(5) == 0
+
+
+def test_api_size_names_are_preprocessor_macros(tmp_path):
+    """ref/api.h:11-14 spells the per-implementation sizes as macros; code that checks them with #if
+    must compile against include/kyber_api.h too"""
+    import subprocess
+    lines = ['#include "kyber_api.h"']
+    for name, base in (("kyber512", 2), ("kyber512_90s", 2), ("kyber768", 3), ("kyber768_90s", 3), ("kyber1024", 4), ("kyber1024_90s", 4)):
+        pk, sk, ct = kyber_amd.sizes(base)
+        for field, val in (("PUBLICKEYBYTES", pk), ("SECRETKEYBYTES", sk), ("CIPHERTEXTBYTES", ct), ("BYTES", 32)):
+            lines += ["#if pqcrystals_%s_hip_%s != %d" % (name, field, val), "#error %s %s" % (name, field), "#endif"]
+    src = tmp_path / "sizes.c"
+    src.write_text("\n".join(lines) + "\nint main(void) { return 0; }\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "sizes.o")], check=True)
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -58,11 +58,13 @@ def test_noalloc_rejects_oversize_and_bad_arguments():
                                          ctypes.c_void_p(sk.data_ptr()), None) == 0
 
 
-def test_noalloc_can_be_captured_in_a_graph(oracle):
+@pytest.mark.parametrize("n90", [0, 1])
+def test_noalloc_can_be_captured_in_a_graph(oracle, n90):
     """The callers this entry point exists for: under stream capture nothing may allocate.  The
     first call (outside capture) takes the scratch array's address; a captured call replays
-    with the same bytes as kyber_batch_dec_dev, also after an input changed in place."""
-    kem = kyber_amd.KyberHip(3)
+    with the same bytes as kyber_batch_dec_dev, also after an input changed in place.  Both the
+    SHAKE and the 90s kernel sequences (the AES launches pick their workgroup size on the host)."""
+    kem = kyber_amd.KyberHip(3, n90)
     n = 1024
     ct, sk = _instances(kem, n, 4242, oracle)
     want = kem.dec_dev(ct, sk)
@@ -85,3 +87,43 @@ def test_noalloc_can_be_captured_in_a_graph(oracle):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, kem.dec_dev(ct, sk)) and not torch.equal(out[1], want[1])
+
+
+def test_noalloc_eager_calls_on_two_streams_are_ordered(oracle):
+    """Outside capture the library orders calls that share the scratch array: back-to-back calls on
+    two streams, with nothing between them, both give kyber_batch_dec_dev's bytes."""
+    kem = kyber_amd.KyberHip(3)
+    n = kl.noalloc_max_n()
+    cta, ska = _instances(kem, n, 91, oracle)
+    ctb, skb = _instances(kem, n, 92, oracle)
+    wa, wb = kem.dec_dev(cta, ska), kem.dec_dev(ctb, skb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        oa = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+        ob = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            kem.dec_dev_noalloc(cta, ska, oa)
+        with torch.cuda.stream(s2):
+            kem.dec_dev_noalloc(ctb, skb, ob)
+        with torch.cuda.stream(s1):
+            kem.dec_dev_noalloc(ctb, skb, ob)
+        torch.cuda.synchronize()
+        assert torch.equal(oa, wa) and torch.equal(ob, wb)
+
+
+def test_release_wipes_and_everything_comes_back(oracle):
+    """kyber_hip_release covers every device the library has touched and the scratch array's
+    contents; the next calls rebuild what they need"""
+    kem = kyber_amd.KyberHip(3, 1)
+    ct, sk = _instances(kem, 500, 7, oracle)
+    want = kem.dec_dev(ct, sk)
+    out = torch.zeros((500, 32), dtype=torch.uint8, device="cuda")
+    kem.dec_dev_noalloc(ct, sk, out)
+    assert kl.library().kyber_hip_release() == 0
+    assert kl.library().kyber_hip_release() == 0
+    out.zero_()
+    kem.dec_dev_noalloc(ct, sk, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(kem.dec_dev(ct, sk), want)
