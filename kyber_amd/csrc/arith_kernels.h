@@ -350,7 +350,10 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
 // One 32-lane group per instance, as in k_enc_arith.  The ciphertext is staged
 // in LDS with 16-byte loads (its 10/11-bit fields start at byte offsets that
 // would otherwise cost ten single-byte global loads per work-item and
-// polynomial); s^ arrives as 12 key bytes per work-item and polynomial.
+// polynomial) and read back with aligned 32-bit loads (decompress_contig_lds32:
+// same-box A/B 0.495 -> 0.471 ms per 2^19 against 16-bit loads); s^ arrives as
+// 12 key bytes per work-item and polynomial.
+// (72 VGPRs for K = 3: seven wavefronts per SIMD; a bound of eight spills)
 template <class P>
 __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
                                                    size_t sk_stride, uint8_t* __restrict__ small) {
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
     for (int j = G::begin(g); j < G::end(g); j++) {
       int c[8];
       float u[8], s[8];
-      decompress_contig<P::DU>(ctb[li] + P::UB * j, w.t, c);
+      decompress_contig_lds32<P::DU>(ctb[li] + P::UB * j, w.t, c);
       i2f8(c, u);
       f_ntt_fwd(wk[w.g], ztab, w.t, u);  // centred, |u| <= 1665
       frombytes12(sb[j][0], sb[j][1], sb[j][2], c);
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restr
   for (int k = 0; k < 8; k++) acc[k] = fred(acc[k]);
   f_ntt_inv(wk[w.g], ztab, w.t, acc);
   int v[8];
-  decompress_contig<P::DV>(ctb[li] + P::UB * K, w.t, v);
+  decompress_contig_lds32<P::DV>(ctb[li] + P::UB * K, w.t, v);
   unsigned byte = 0;  // poly_tomsg: bit k = round(2 x / q) & 1       ref/poly.c:180-194
 #pragma unroll
   for (int k = 0; k < 8; k++) byte |= fcompress<1>((float)v[k] - acc[k]) << k;  // |.| <= 3328 + 1668

@@ -317,6 +317,36 @@ __device__ __forceinline__ void decompress_contig(const uint8_t* in, int t, int 
   }
 }
 
+// The same from an LDS copy of the byte string (`in` 4-byte aligned), with aligned 32-bit loads:
+// D bytes starting at any byte offset lie within (D + 6) / 4 consecutive dwords, which are read
+// whole and shifted into place.  D = 10 takes three loads instead of five 16-bit ones, D = 11 four
+// instead of eleven single bytes.  Reads up to 7 bytes past the field's end: the caller's buffer
+// holds the whole ciphertext (the last polynomial, v, has D = 4 or 5, where the excess is 0 or 3
+// bytes inside its own 32 D bytes).
+template <int D>
+__device__ __forceinline__ void decompress_contig_lds32(const uint8_t* in, int t, int (&c)[8]) {
+  constexpr int NW = (D % 4 == 0) ? D / 4 : (D + 6) / 4;
+  const unsigned o = (unsigned)(D * t);
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(in) + (o >> 2);
+  const unsigned sh = (o & 3u) * 8u;
+  uint32_t w[NW + 1];
+#pragma unroll
+  for (int i = 0; i < NW; i++) w[i] = p[i];
+  w[NW] = 0;
+  uint32_t x[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 3 && i < NW; i++) x[i] = (D % 4 == 0) ? w[i] : __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+  const unsigned long long lo = (unsigned long long)x[1] << 32 | x[0], hi = x[2];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int pos = D * k;
+    unsigned long long v = 0;
+    if (pos < 64) v = lo >> pos;
+    if (pos + D > 64) v |= (pos >= 64) ? hi >> (pos - 64) : hi << (64 - pos);
+    c[k] = decompress1<D>((unsigned)v);
+  }
+}
+
 // ---------------------------------------------------------------- message
 // byte t of the message <-> coefficients 8t..8t+7.  ref/poly.c:155-194
 __device__ __forceinline__ void frommsg_contig(unsigned byte, int (&c)[8]) {
