@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 for f in glob.glob(os.path.join(G, run + "_bench_*.json")):
     shutil.copy(f, os.path.join(P, os.path.basename(f).replace(run + "_", out + "_")))
+for f in glob.glob(os.path.join(G, run + "_smi_during_bench.txt")):
+    shutil.copy(f, os.path.join(P, out + "_smi_during_bench.txt"))
 for tag in ("kem", "ntt", "kem90s"):
     for f in glob.glob(os.path.join(G, "%s_prof_%s" % (run, tag), "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(P, "%s_%s_kernel_stats.csv" % (out, tag)))
