@@ -225,3 +225,28 @@ def test_cached_multiplicand_accumulation_stays_exact():
     # inverse transform without the final 1/128: outputs are sums of two reduced values,
     # and the compression input bound of test_float_compress_formula_is_exact still holds
     assert 2 * 1665 + 2 + 1665 <= 5000
+
+
+def test_bench_work_model_adds_up():
+    """bench.py prices every pipeline kernel per instance (kernel_work); over one encaps + decaps the
+    Keccak kernels' lane-ops must add up to SURVEY §3.4's permutation counts (61 / 100 / 155), with
+    and without a shared key pair, and the 90s model to lane_ops_per_encdec"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    P = bench.KECCAK_LANE_OPS
+    for k, want in ((2, 61), (3, 100), (4, 155)):
+        assert bench.perms_per_encdec(k) == want
+        for shared in (False, True):
+            w = lambda name: bench.kernel_work(name, k, 0, shared)
+            enc = ["k_enc_pre", "k_prf", "k_post"] + ([] if shared else ["k_sample_matrix"])
+            dec = ["k_dec_mid", "k_prf", "k_post"] + ([] if shared else ["k_sample_matrix"])
+            total = sum(w(n)[0] for n in enc + dec)
+            assert total == bench.perms_per_encdec(k, shared) * P, (k, shared)
+            assert bench.lane_ops_per_encdec(k, 0, shared) == total
+        # 90s: the symmetric kernels of an encaps + decaps are what lane_ops_per_encdec(k, 1) prices
+        names = ["k90_enc_pre", "k90_sample_matrix", "k90_prf", "k90_post", "k90_dec_mid", "k90_sample_matrix", "k90_prf", "k90_post"]
+        assert sum(bench.kernel_work(n, k, 1)[0] for n in names) == bench.lane_ops_per_encdec(k, 1)
+    assert bench.kernel_work("k_sample_matrix_tail", 3, 0) is None and bench.kernel_work("k_sample_matrix", 3, 0, True) is None
+    # compulsory bytes: an encapsulation reads pk + coins and writes ct + ss (SURVEY §8(d): 2336 B for Kyber768)
+    assert 1184 + 32 + 1088 + 32 == 2336
