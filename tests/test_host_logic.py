@@ -250,3 +250,66 @@ def test_bench_work_model_adds_up():
     assert bench.kernel_work("k_sample_matrix_tail", 3, 0) is None and bench.kernel_work("k_sample_matrix", 3, 0, True) is None
     # compulsory bytes: an encapsulation reads pk + coins and writes ct + ss (2336 B for Kyber768)
     assert 1184 + 32 + 1088 + 32 == 2336
+
+
+def test_wide_engine_products_and_reductions_are_exact():
+    """kyber_amd/csrc/wpoly.h in numpy: fmulc (three FMAs), fred_canon and fmulc_canon (floor quotient)
+    over their whole input ranges.  An fp32 FMA is modelled as float32(float64(a) * float64(b) + float64(c)):
+    for these operand sizes the float64 sum is exact, or -- where it is not (fred_canon's quotient) -- never
+    close enough to a rounding boundary for the second rounding to matter, which is asserted."""
+    Q = 3329
+    f32, f64 = np.float32, np.float64
+    M, QINV = f32(12582912.0), f32(1.0) / f32(3329.0)
+    QM = f32(3329.0) * M
+    assert float(QM) == 3329 * 12582912  # q * magic is an fp32 number
+
+    def fma(a, b, c):
+        return (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+    def fmulc(b, z):
+        zf = np.full_like(b, f32(z))
+        zq = np.full_like(b, f32(z) * QINV)
+        k = fma(b, zq, np.full_like(b, M))
+        m = fma(k, np.full_like(b, f32(-Q)), np.full_like(b, QM))
+        return fma(zf, b, m)
+
+    brv7 = lambda i: int(format(i, "07b")[::-1], 2)
+    cen = lambda v: (v % Q) - (Q if (v % Q) > Q // 2 else 0)
+    consts = sorted({cen(pow(17, brv7(i), Q)) for i in range(128)} | {-cen(pow(17, brv7(i), Q)) for i in range(64, 128)}
+                    | {169, 512, -266, -26, 1652})
+    b = np.arange(-10078, 10079, dtype=np.int64)
+    for z in consts:
+        if abs(z) * 10078 >= 1 << 24:
+            bb = b[np.abs(b) * abs(z) < (1 << 24)]
+        else:
+            bb = b
+        r = fmulc(bb.astype(f32), z).astype(np.int64)
+        assert np.array_equal(np.mod(r - z * bb, Q), np.zeros_like(bb)), z
+        assert np.abs(r).max() <= 1665, (z, np.abs(r).max())
+
+    def fred_canon(x):
+        xs = (x.astype(f64) - 1664.0)
+        exact = xs * f64(QINV) + f64(M)                       # may be rounded by float64 ...
+        frac = np.abs(exact - np.floor(exact) - 0.5)
+        assert frac.min() > 1e-6                              # ... but never near a half: both roundings agree
+        k = exact.astype(f32)
+        return x + fma(k, np.full_like(x, f32(-Q)), np.full_like(x, QM))
+
+    xs = np.concatenate([np.arange(-(1 << 17), 1 << 17),
+                         (np.arange(-5039, 5040)[:, None] * Q + np.array([0, 1, 2, 1663, 1664, 1665, 1666, 3327, 3328])).ravel()])
+    xs = xs[np.abs(xs) < (1 << 24)]
+    r = fred_canon(xs.astype(f32)).astype(np.int64)
+    assert np.array_equal(r, np.mod(xs, Q))
+
+    def fmulc_canon(b, z):
+        zf = np.full_like(b, f32(z))
+        p = fma(zf, b, np.full_like(b, f32(-1664.0)))
+        exact = p.astype(f64) * f64(QINV) + f64(M)
+        assert np.abs(exact - np.floor(exact) - 0.5).min() > 1e-6
+        k = exact.astype(f32)
+        return fma(zf, b, fma(k, np.full_like(b, f32(-Q)), np.full_like(b, QM)))
+
+    bb = np.arange(-6660, 6661, dtype=np.int64)
+    for z in (512, -266, -26, 1652, 1664, -1664):
+        r = fmulc_canon(bb.astype(f32), z).astype(np.int64)
+        assert np.array_equal(r, np.mod(z * bb, Q)), z
