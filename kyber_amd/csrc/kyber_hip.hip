@@ -809,7 +809,9 @@ struct HostCtx {
   Streams S;
   uint8_t* staging = nullptr;
   size_t cap = 0;
+  uint8_t* mirror = nullptr;  // pinned host copy of the staging area's layout, for small batches (host_pipeline)
 };
+constexpr size_t HOST_MIRROR_BYTES = 1u << 20;  // Kyber768: up to n = 256 (the CPU moves these bytes, as the runtime would for pageable memory)
 HostCtx* g_host[MAX_DEV] = {};
 std::mutex g_host_mu[MAX_DEV];
 
@@ -856,6 +858,11 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
   HostCtx* ctx = nullptr;
   if (int rc = host_ctx(total, &ctx)) return rc;
   Streams& S = ctx->S;
+  // A batch that fits one pass has nothing to overlap: copies and kernels go down ONE stream in order,
+  // which saves the two cross-stream event hops and two stream synchronisations of the general path
+  // (tens of microseconds of a 0.2 ms call, DESIGN 5 "small batches").
+  const bool single = slots == 1;
+  const hipStream_t s_in = single ? S.comp : S.in, s_out = single ? S.comp : S.out;
   // Every early return below leaves copies into or out of caller memory (and out
   // of Coins' buffer) in flight: drain the three streams before the caller may
   // free anything.  Disarmed after the final synchronisation of the normal path.
@@ -875,11 +882,49 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
     din[s].resize(ins.size());
     dout[s].resize(outs.size());
   }
+  // Small single-pass batches go through a pinned mirror of the staging area: inputs are gathered into
+  // it by the CPU and reach the device as ONE copy, outputs come back as ONE copy and are scattered by
+  // the CPU -- two DMA commands and one wait per call instead of a command per buffer, each of which,
+  // from or to pageable memory, is staged by the runtime and (device to host) waited for on its own.
+  if (single && total <= HOST_MIRROR_BYTES) {
+    if (!ctx->mirror) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->mirror), HOST_MIRROR_BYTES, hipHostMallocDefault));
+    uint8_t* mir = ctx->mirror;
+    size_t off = 0;
+    for (size_t i = 0; i < ins.size(); i++) {
+      const size_t b = ins[i].once ? ins[i].per : ins[i].per * n;
+      din[0][i] = cur + off;
+      std::memcpy(mir + off, ins[i].p, b);
+      off += pad(b);
+    }
+    const size_t in_bytes = off;
+    for (size_t i = 0; i < outs.size(); i++) {
+      dout[0][i] = cur + off;
+      off += pad(outs[i].per * n);
+    }
+    struct WipeMirror {  // coins, secret keys and shared secrets passed through it
+      uint8_t* p;
+      size_t b;
+      hipStream_t st;
+      bool idle = false;  // set once the stream has been waited for: nothing can land in the mirror after the wipe
+      ~WipeMirror() {
+        if (!idle) (void)hipStreamSynchronize(st);
+        explicit_bzero(p, b);
+      }
+    } wipe{mir, off, S.comp};
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(cur, mir, in_bytes, hipMemcpyHostToDevice, S.comp));
+    if (int rc = f(n, din[0].data(), dout[0].data(), S.comp)) return rc;
+    if (off > in_bytes) HIP_TRY(hipMemcpyAsync(mir + in_bytes, cur + in_bytes, off - in_bytes, hipMemcpyDeviceToHost, S.comp));
+    HIP_TRY(hipStreamSynchronize(S.comp));
+    wipe.idle = true;
+    drain.armed = false;
+    for (size_t i = 0; i < outs.size(); i++) std::memcpy(outs[i].p, mir + (dout[0][i] - cur), outs[i].per * n);
+    return 0;
+  }
   for (size_t i = 0; i < ins.size(); i++) {
     if (ins[i].once) {
       din[0][i] = din[1][i] = cur;
       cur += pad(ins[i].per);
-      HIP_TRY(hipMemcpyAsync(din[0][i], ins[i].p, ins[i].per, hipMemcpyHostToDevice, S.in));
+      HIP_TRY(hipMemcpyAsync(din[0][i], ins[i].p, ins[i].per, hipMemcpyHostToDevice, s_in));
     } else {
       for (int s = 0; s < slots; s++) {
         din[s][i] = cur;
@@ -899,20 +944,24 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
     if (c >= 2) HIP_TRY(hipStreamWaitEvent(S.in, S.comp_done[s], 0));  // slot's inputs consumed
     for (size_t i = 0; i < ins.size(); i++)
       if (!ins[i].once)
-        HIP_TRY(hipMemcpyAsync(din[s][i], ins[i].p + o * ins[i].per, m * ins[i].per, hipMemcpyHostToDevice, S.in));
-    HIP_TRY(hipEventRecord(S.in_done[s], S.in));
-    HIP_TRY(hipStreamWaitEvent(S.comp, S.in_done[s], 0));
+        HIP_TRY(hipMemcpyAsync(din[s][i], ins[i].p + o * ins[i].per, m * ins[i].per, hipMemcpyHostToDevice, s_in));
+    if (!single) {
+      HIP_TRY(hipEventRecord(S.in_done[s], S.in));
+      HIP_TRY(hipStreamWaitEvent(S.comp, S.in_done[s], 0));
+    }
     if (c >= 2) HIP_TRY(hipStreamWaitEvent(S.comp, S.out_done[s], 0));  // slot's outputs drained
     if (int rc = f(m, din[s].data(), dout[s].data(), S.comp)) return rc;
-    HIP_TRY(hipEventRecord(S.comp_done[s], S.comp));
-    HIP_TRY(hipStreamWaitEvent(S.out, S.comp_done[s], 0));
+    if (!single) {
+      HIP_TRY(hipEventRecord(S.comp_done[s], S.comp));
+      HIP_TRY(hipStreamWaitEvent(S.out, S.comp_done[s], 0));
+    }
     for (size_t i = 0; i < outs.size(); i++)
-      HIP_TRY(hipMemcpyAsync(outs[i].p + o * outs[i].per, dout[s][i], m * outs[i].per, hipMemcpyDeviceToHost, S.out));
-    HIP_TRY(hipEventRecord(S.out_done[s], S.out));
+      HIP_TRY(hipMemcpyAsync(outs[i].p + o * outs[i].per, dout[s][i], m * outs[i].per, hipMemcpyDeviceToHost, s_out));
+    if (!single) HIP_TRY(hipEventRecord(S.out_done[s], S.out));
   }
-  HIP_TRY(hipStreamSynchronize(S.out));
+  if (!single) HIP_TRY(hipStreamSynchronize(S.out));
   HIP_TRY(hipStreamSynchronize(S.comp));
-  HIP_TRY(hipStreamSynchronize(S.in));
+  if (!single) HIP_TRY(hipStreamSynchronize(S.in));
   drain.armed = false;
   return 0;
 }
@@ -1650,6 +1699,10 @@ static int release_device(int dev) {
     if (c->staging) {
       HIP_TRY(hipMemset(c->staging, 0, c->cap));  // secret keys and shared secrets were staged here
       HIP_TRY(hipFree(c->staging));
+    }
+    if (c->mirror) {  // wiped after every call (host_pipeline)
+      HIP_TRY(hipHostFree(c->mirror));
+      c->mirror = nullptr;
     }
     delete c;  // streams and events
     g_host[dev] = nullptr;
