@@ -97,7 +97,12 @@ int kyber_batch_dec_mgpu_dev(int k, int nineties, int ndev, const int *devices, 
  * any thread, on any stream -- are serialised by the library: a per-device lock
  * orders the launches and each call's stream first waits for an event recorded
  * behind the previous call's last kernel, so they may be issued concurrently
- * but do not run concurrently. */
+ * but do not run concurrently.  Batches of up to 8192 instances (encapsulation;
+ * decapsulation from 1024) expand their matrices on a second, library-owned
+ * stream beside the hashes: it starts behind everything already queued on
+ * `stream` and `stream` waits for it before the arithmetic, so the caller sees
+ * one ordered stream either way.  Under stream capture the call stays on
+ * `stream` alone. */
 int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t *pk, uint8_t *sk, const uint8_t *coins, void *stream);
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t *ct, uint8_t *ss, const uint8_t *pk, const uint8_t *coins, void *stream);
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t *ss, const uint8_t *ct, const uint8_t *sk, void *stream);

@@ -254,6 +254,81 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
   }
 }
 
+// ---- small batches: the matrix expansion beside the hashes --------------------------------
+// Up to a few thousand instances no kernel fills the chip and a call's time is its chain of dependent
+// launches, each as long as its longest lane (a permutation on one lane takes ~10 us).  The matrix
+// expansion (three dependent permutations) needs only rho, so for such batches it runs on a second
+// stream beside the hashes in front of it (encapsulation: H(m), H(pk), G; decapsulation: the
+// decryption and G) and the caller's stream picks it up again before the PRF.  Not under stream
+// capture, and not in the no-allocation entry point (one stream there, by contract).
+// The two cross-stream hops cost ~25 us themselves (profiles/r03_ab_latency_side_stream.txt): an
+// encapsulation hides the expansion behind eleven permutations and gains at every size (n = 1: -4 %,
+// 256: -14 %, 4096: -8 %); a decapsulation has only the decryption and one permutation in front, gains
+// 4 % at n = 4096 and loses 3 % at n = 1, so it forks from SIDE_MIN_N_DEC instances on.
+constexpr size_t SIDE_MAX_N = 8192, SIDE_MIN_N_DEC = 1024;
+struct Side {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+Side g_side[MAX_DEV];  // under g_dev_mu like the workspace
+
+Side* side_for(size_t n, hipStream_t st) {
+  if (n > SIDE_MAX_N) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  Side& sd = g_side[dev];
+  if (!sd.s) {
+    Side t;
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) {
+      if (t.s) (void)hipStreamDestroy(t.s);
+      if (t.fork) (void)hipEventDestroy(t.fork);
+      (void)hipGetLastError();
+      return nullptr;  // the call then runs on one stream, as large batches do
+    }
+    sd = t;
+  }
+  return &sd;
+}
+// everything queued on st so far (the previous user of the workspace included) comes first
+int side_begin(Side* sd, hipStream_t st) {
+  HIP_TRY(hipEventRecord(sd->fork, st));
+  HIP_TRY(hipStreamWaitEvent(sd->s, sd->fork, 0));
+  return 0;
+}
+int side_end(Side* sd) {
+  HIP_TRY(hipEventRecord(sd->join, sd->s));
+  return 0;
+}
+int side_join(Side* sd, hipStream_t st) {
+  HIP_TRY(hipStreamWaitEvent(st, sd->join, 0));
+  return 0;
+}
+// expand_matrix on the side stream when there is one, else on st; *pending tells the caller to join
+template <class P, bool N90>
+int expand_matrix_beside(Side* sd, bool* pending, int insts, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat,
+                         Layout<P>& L, hipStream_t st) {
+  if (!sd) return expand_matrix<P, N90>(insts, rho, rho_stride, transposed, mat, L, st);
+  if (int rc = side_begin(sd, st)) return rc;
+  if (int rc = expand_matrix<P, N90>(insts, rho, rho_stride, transposed, mat, L, sd->s)) return rc;
+  if (int rc = side_end(sd)) return rc;
+  *pending = true;
+  return 0;
+}
+#define SIDE_JOIN(sd, pending, st)                  \
+  do {                                              \
+    if (pending) {                                  \
+      if (int rc_ = side_join(sd, st)) return rc_;  \
+      pending = false;                              \
+    }                                               \
+  } while (0)
+
 // ---- the three pipelines (device pointers) -----------------------------------
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
@@ -303,10 +378,12 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
   const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
+  Side* sd = side_for(n, st);
+  bool pending = false;
   if (shared && !pmat) {
+    if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
     if constexpr (N90) RUN("k90_hash_pk", st, k90_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
     else RUN("k_hash_pk", st, k_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
-    if (int rc = expand_matrix<P, N90>(1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
   }
   const uint8_t* hpk = shared ? (pmat ? phpk : L.hpk) : nullptr;
   const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
@@ -315,13 +392,14 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = pk + o * pk_stride;
     uint8_t* c = ct + o * P::CTB;
+    if (!shared)
+      if (int rc = expand_matrix_beside<P, N90>(sd, &pending, m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     } else {
       RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     }
-    if (!shared)
-      if (int rc = expand_matrix<P, N90>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
+    SIDE_JOIN(sd, pending, st);
     if constexpr (N90) {
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
@@ -342,24 +420,26 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 // the kernel sequence of a decapsulation over a workspace that is already laid out
 template <class P, bool N90>
 int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st,
-            const int16_t* pmat = nullptr) {
+            const int16_t* pmat = nullptr, Side* sd = nullptr) {
   const bool shared = sk_stride == 0;
+  bool pending = false;
   if (shared && !pmat)
-    if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
+    if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
   const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
   const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * sk_stride;
+    if (!shared)
+      if (int rc = expand_matrix_beside<P, N90>(sd, &pending, m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
     if constexpr (N90) {
       RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
       RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, sk_stride, L.small));
     }
-    if (!shared)
-      if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
+    SIDE_JOIN(sd, pending, st);
     if constexpr (N90) {
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
@@ -386,7 +466,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat);
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, n >= SIDE_MIN_N_DEC ? side_for(n, st) : nullptr);
 }
 
 // ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
@@ -1685,10 +1765,16 @@ int kyber_hip_set_tail_capacity(size_t records) {
 static int release_device(int dev) {
   std::lock_guard<std::mutex> hlk(g_host_mu[dev]);  // same order as the host-pointer calls: host lock, then workspace lock
   std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
-  const bool any = g_ws[dev].base || g_host[dev] || g_scratch_ptr[dev];
+  const bool any = g_ws[dev].base || g_host[dev] || g_scratch_ptr[dev] || g_side[dev].s;
   if (!any) return 0;
   HIP_TRY(hipSetDevice(dev));
   HIP_TRY(hipDeviceSynchronize());
+  if (g_side[dev].s) {
+    (void)hipStreamDestroy(g_side[dev].s);
+    (void)hipEventDestroy(g_side[dev].fork);
+    (void)hipEventDestroy(g_side[dev].join);
+    g_side[dev] = Side{};
+  }
   if (g_ws[dev].base) {
     HIP_TRY(hipMemset(g_ws[dev].base, 0, g_ws[dev].bytes));  // sigma, r, m, Kbar, PRF bytes of the last call
     HIP_TRY(hipFree(g_ws[dev].base));

@@ -101,3 +101,44 @@ def test_multi_device_rejects_absent_device():
     kem = kyber_amd.KyberHip(3)
     with pytest.raises(kl.KyberHipError, match="not present"):
         kem.keypair_mgpu(_coins(4, 64, 1), [0, 63])
+
+
+@pytest.mark.parametrize("n90", [0, 1])
+@pytest.mark.parametrize("n", [1, 300, 2048, 8192, 8193])
+def test_small_batch_paths_on_user_streams(oracle, n, n90):
+    """Small batches take their own routes through the library (kyber_hip.hip): host calls up to 1 MiB go
+    through the pinned mirror on one stream, encapsulations up to 8192 instances (decapsulations from
+    1024) expand the matrix on a second stream beside the hashes.  Device-pointer calls on two user
+    streams in turn, host calls in between: every byte must be the oracle's, on both sides of the
+    thresholds, and calls queued back to back on different streams must not disturb each other."""
+    import torch
+    k = 3
+    kem = kyber_amd.KyberHip(k, n90)
+    kc, ec, ec2 = _coins(n, 64, 900 + n), _coins(n, 32, 901 + n), _coins(n, 32, 902 + n)
+    opk, osk = oracle.keypair(k, kc, n90)
+    oct_, oss = oracle.enc(k, opk, ec, n90)
+    oct2, oss2 = oracle.enc(k, opk, ec2, n90)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dkc, dec1, dec2 = dev(kc), dev(ec), dev(ec2)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        pk, sk = kem.keypair_dev(dkc)
+        ct, ss = kem.enc_dev(pk, dec1)
+    s2.wait_stream(s1)  # s2 reads pk, sk, ct: data dependencies are the caller's; the workspace is the library's
+    with torch.cuda.stream(s2):
+        ct2, ssb = kem.enc_dev(pk, dec2)
+        ss_dec = kem.dec_dev(ct, sk)
+    with torch.cuda.stream(s1):
+        s1.wait_stream(s2)
+        ss_dec2 = kem.dec_dev(ct2, sk)
+    torch.cuda.synchronize()
+    assert np.array_equal(pk.cpu().numpy(), opk) and np.array_equal(sk.cpu().numpy(), osk)
+    assert np.array_equal(ct.cpu().numpy(), oct_) and np.array_equal(ss.cpu().numpy(), oss)
+    assert np.array_equal(ct2.cpu().numpy(), oct2) and np.array_equal(ssb.cpu().numpy(), oss2)
+    assert np.array_equal(ss_dec.cpu().numpy(), oss) and np.array_equal(ss_dec2.cpu().numpy(), oss2)
+    # host-pointer calls of the same batch (mirror path for the small ones), twice in a row
+    for _ in range(2):
+        hct, hss = kem.enc(opk, ec)
+        assert np.array_equal(hct, oct_) and np.array_equal(hss, oss)
+        assert np.array_equal(kem.dec(hct, osk), oss)
