@@ -23,6 +23,7 @@
 #include "../../include/kyber_api.h"
 #include "../../include/mlkem_batch.h"
 #include "kem_kernels_90s.h"
+#include "keccak_split.h"
 #include "arith_launch.h"
 
 using namespace ky;
@@ -228,6 +229,13 @@ inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
     prof_end(name, st, ev_a_);    \
   } while (0)
 
+// An FO-hash kernel of kem_kernels.h, or for small batches its stand-in on work-item pairs (keccak_split.h)
+#define RUN_HASH(name, st, m_, kern, kern2, ...)                                                                                  \
+  do {                                                                                                                            \
+    if ((size_t)(m_) <= SPLIT_MAX_N) RUN(name, st, kern2<<<blocks(2 * (size_t)(m_), SPLIT_WG), SPLIT_WG, 0, st>>>(__VA_ARGS__));     \
+    else RUN(name, st, kern<<<blocks((m_), sponge_wg(m_)), sponge_wg(m_), 0, st>>>(__VA_ARGS__));                                   \
+  } while (0)
+
 template <class P>
 int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transposed, int16_t* mat, uint32_t* tailq,
                   uint32_t tail_cap, hipStream_t st) {
@@ -344,7 +352,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     const uint8_t* c = coins + o * 64;
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
     if constexpr (N90) RUN("k90_kp_pre", st, k90_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
-    else RUN("k_kp_pre", st, k_kp_pre<<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small));
+    else RUN_HASH("k_kp_pre", st, m, k_kp_pre, k2_kp_pre, m, c, L.small);
     if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
     if constexpr (N90) {
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * 2 * P::K, (m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
@@ -355,7 +363,7 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     if constexpr (N90) {
       RUN("k90_kp_post", st, k90_kp_post<P><<<blocks(m, 256), 256, 0, st>>>(m, c, p, s));
     } else {
-      RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, p, s));
+      RUN_HASH("k_kp_post", st, m, k_kp_post<P>, k2_kp_post<P>, m, c, p, s);
     }
   }
   return 0;
@@ -383,7 +391,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
   if (shared && !pmat) {
     if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
     if constexpr (N90) RUN("k90_hash_pk", st, k90_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
-    else RUN("k_hash_pk", st, k_hash_pk<P><<<1, 64, 0, st>>>(pk, L.hpk));
+    else RUN("k_hash_pk", st, k2_hash_pk<P><<<1, SPLIT_WG, 0, st>>>(pk, L.hpk));
   }
   const uint8_t* hpk = shared ? (pmat ? phpk : L.hpk) : nullptr;
   const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
@@ -397,7 +405,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     if constexpr (N90) {
       RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
     } else {
-      RUN("k_enc_pre", st, k_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, hpk, L.small));
+      RUN_HASH("k_enc_pre", st, m, k_enc_pre<P>, k2_enc_pre<P>, m, coins + o * 32, p, hpk, L.small);
     }
     SIDE_JOIN(sd, pending, st);
     if constexpr (N90) {
@@ -409,7 +417,7 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, false><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, false><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, nullptr, 0, ss + o * 32));
+      RUN_HASH("k_post", st, m, (k_post<P, false>), (k2_post<P, false>), m, c, L.small, nullptr, 0, ss + o * 32);
     }
   }
   return 0;
@@ -437,7 +445,7 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
-      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, sk_stride, L.small));
+      RUN_HASH("k_dec_mid", st, m, k_dec_mid<P>, k2_dec_mid<P>, m, s, sk_stride, L.small);
     }
     SIDE_JOIN(sd, pending, st);
     if constexpr (N90) {
@@ -451,7 +459,7 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
-      RUN("k_post", st, k_post<P, true><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
+      RUN_HASH("k_post", st, m, (k_post<P, true>), (k2_post<P, true>), m, c, L.small, s, sk_stride, ss + o * 32);
     }
   }
   return 0;

@@ -15,7 +15,8 @@ L = kl.library()
 N90 = int(len(sys.argv) > 1 and sys.argv[1] == "90s")   # tools/latency.py 90s: Kyber768-90s
 kem = kyber_amd.KyberHip(3, N90)
 p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-for n in (1, 16, 256, 4096, 16384):
+SIZES = tuple(int(x) for x in __import__("os").environ.get("KY_LAT_SIZES", "1,16,256,4096,8192,16384").split(","))  # KY_LAT_SIZES=32768,65536: other sizes
+for n in SIZES:
     rng = np.random.default_rng(n)
     kc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
     ec = rng.integers(0, 256, (n, 32), dtype=np.uint8)
