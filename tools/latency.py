@@ -59,3 +59,29 @@ with kem.prepare_pk(pk1[0]) as ppk, kem.prepare_sk(sk1[0]) as psk:
         assert np.array_equal(ss, ss3)
         print("n=%5d  one key: enc shared %7.1f us  prepared %7.1f us | dec shared %7.1f us  prepared %7.1f us"
               % (n, res["enc_shared"], res["enc_prepared"], res["dec_shared"], res["dec_prepared"]))
+
+# data resident in HBM: the device-pointer calls, enqueue + synchronise (what a serving loop that
+# keeps keys and ciphertexts on the device pays per batch)
+import torch  # noqa: E402
+
+for n in (1, 256, 4096, 16384, 65536):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = kem.keypair_dev(kc)
+    ct, ss = kem.enc_dev(pk, ec)
+    ss2 = torch.empty_like(ss)
+    res = {}
+    for name, fn in (("keypair", lambda: kem.keypair_dev(kc, pk, sk)), ("enc", lambda: kem.enc_dev(pk, ec, ct, ss)),
+                     ("dec", lambda: kem.dec_dev(ct, sk, ss2))):
+        ts = []
+        for _ in range(200):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name] = np.median(ts) * 1e6
+    assert torch.equal(ss, ss2)
+    print("n=%5d  device pointers: keypair %7.1f us  enc %7.1f us  dec %7.1f us" % (n, res["keypair"], res["enc"], res["dec"]))

@@ -21,6 +21,8 @@ for tag in ("kem", "ntt", "kem90s"):
 summ = os.path.join(ROOT, "tools", "pmc_summarize.py")
 for tag, name in (("", "kem"), ("_ntt", "ntt")):
     sq = [os.path.join(G, "pmc_%s%s_sq%d" % (run, tag, i)) for i in (1, 2)]
+    if not all(os.path.isdir(d) for d in sq):  # tools/round_profiles.sh <run> bench: no counter passes in this run
+        continue
     with open(os.path.join(P, "%s_pmc_sq_%s.txt" % (out, name)), "w") as fh:
         subprocess.run([sys.executable, summ] + sq, stdout=fh, check=True)
     tr = [os.path.join(G, "pmc_%s%s_%s" % (run, tag, c)) for c in ("fetch", "write")]
