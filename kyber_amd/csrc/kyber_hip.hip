@@ -266,14 +266,18 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 // Up to a few thousand instances no kernel fills the chip and a call's time is its chain of dependent
 // launches, each as long as its longest lane (a permutation on one lane takes ~10 us).  The matrix
 // expansion (three dependent permutations) needs only rho, so for such batches it runs on a second
-// stream beside the hashes in front of it (encapsulation: H(m), H(pk), G; decapsulation: the
-// decryption and G) and the caller's stream picks it up again before the PRF.  Not under stream
+// stream beside the hashes in front of it (encapsulation: H(m), H(pk), G) and the caller's stream
+// picks it up again before the PRF.  Not under stream
 // capture, and not in the no-allocation entry point (one stream there, by contract).
-// The two cross-stream hops cost ~25 us themselves (profiles/r03_ab_latency_side_stream.txt): an
-// encapsulation hides the expansion behind eleven permutations and gains at every size (n = 1: -4 %,
-// 256: -14 %, 4096: -8 %); a decapsulation has only the decryption and one permutation in front, gains
-// 4 % at n = 4096 and loses 3 % at n = 1, so it forks from SIDE_MIN_N_DEC instances on.
-constexpr size_t SIDE_MAX_N = 8192, SIDE_MIN_N_DEC = 1024;
+// The two cross-stream hops cost ~25 us themselves (profiles/r03_ab_latency_side_stream.txt,
+// r03_ab_latency_side_stream_dev.txt): an encapsulation hides the expansion behind eleven permutations
+// and gains at every size (device pointers, n = 1: 233 -> 215 us, 256: 233 -> 200, 4096: 244 -> 221); a
+// decapsulation has only the decryption and one permutation in front and measured -4 % to +3 %
+// depending on size and on the caller's stream, so it stays on one stream.
+#ifndef KY_SIDE_MAX_N
+#define KY_SIDE_MAX_N 8192  // tools/build_variant.sh noside -DKY_SIDE_MAX_N=0: the A/B of this path
+#endif
+constexpr size_t SIDE_MAX_N = KY_SIDE_MAX_N;
 struct Side {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -292,7 +296,12 @@ Side* side_for(size_t n, hipStream_t st) {
   Side& sd = g_side[dev];
   if (!sd.s) {
     Side t;
-    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess ||
+    // Highest priority: the runtime keeps the hardware queues of a priority level apart from those of the
+    // other levels, so this stream never shares a queue with a caller's (normal-priority) stream --
+    // on a shared queue the fork is a detour, not an overlap (profiles/r03_ab_latency_side_stream_mixed.txt).
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+    if (hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) {
       if (t.s) (void)hipStreamDestroy(t.s);
@@ -428,26 +437,24 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 // the kernel sequence of a decapsulation over a workspace that is already laid out
 template <class P, bool N90>
 int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st,
-            const int16_t* pmat = nullptr, Side* sd = nullptr) {
+            const int16_t* pmat = nullptr) {
   const bool shared = sk_stride == 0;
-  bool pending = false;
   if (shared && !pmat)
-    if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
+    if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
   const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
   const size_t mat_stride = shared ? 0 : (size_t)P::NMAT * 256;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * sk_stride;
-    if (!shared)
-      if (int rc = expand_matrix_beside<P, N90>(sd, &pending, m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
     if constexpr (N90) {
       RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
     } else {
       RUN_HASH("k_dec_mid", st, m, k_dec_mid<P>, k2_dec_mid<P>, m, s, sk_stride, L.small);
     }
-    SIDE_JOIN(sd, pending, st);
+    if (!shared)
+      if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
@@ -474,7 +481,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, n >= SIDE_MIN_N_DEC ? side_for(n, st) : nullptr);
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat);
 }
 
 // ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
