@@ -25,11 +25,13 @@ namespace ky {
 
 // lanes per sponge-pair workgroup: one wavefront = 32 sponges
 constexpr int SPLIT_WG = 64;
-// batches up to this many instances hash on pairs (2 * SPLIT_MAX_N work-items: at most one
-// wavefront per two SIMDs of the chip).  Same-box A/B of the threshold: n = 8192 enc 1111 -> 1043 us,
-// dec 1040 -> 1011; n = 16384 1987 -> 1930, 2293 -> 2259; beyond that the host-pointer calls measured
-// are copy-bound and show nothing either way.
-constexpr size_t SPLIT_MAX_N = 16384;
+// Batches up to this many instances hash on pairs.  Same-box A/B of the threshold, device-pointer calls
+// (profiles/r03_ab_midsize_thresholds.txt): n = 32768 enc 460 -> 437 us; 65536 a tie; 131072 +9 %: from one
+// wavefront per SIMD on, the pair's 240 lane-instructions per round cost more than its shorter chain saves.
+#ifndef KY_SPLIT_MAX_N
+#define KY_SPLIT_MAX_N 32768
+#endif
+constexpr size_t SPLIT_MAX_N = KY_SPLIT_MAX_N;
 
 __device__ __forceinline__ uint32_t ks_other(uint32_t x) {  // the partner's copy of x
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);

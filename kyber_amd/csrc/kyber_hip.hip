@@ -263,7 +263,7 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 }
 
 // ---- small batches: the matrix expansion beside the hashes --------------------------------
-// Up to a few thousand instances no kernel fills the chip and a call's time is its chain of dependent
+// Up to a few ten thousand instances no kernel fills the chip and a call's time is its chain of dependent
 // launches, each as long as its longest lane (a permutation on one lane takes ~10 us).  The matrix
 // expansion (three dependent permutations) needs only rho, so for such batches it runs on a second
 // stream beside the hashes in front of it (encapsulation: H(m), H(pk), G) and the caller's stream
@@ -273,9 +273,10 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 // r03_ab_latency_side_stream_dev.txt): an encapsulation hides the expansion behind eleven permutations
 // and gains at every size (device pointers, n = 1: 233 -> 215 us, 256: 233 -> 200, 4096: 244 -> 221); a
 // decapsulation has only the decryption and one permutation in front and measured -4 % to +3 %
-// depending on size and on the caller's stream, so it stays on one stream.
+// depending on size and on the caller's stream, so it stays on one stream.  Threshold: n = 16384 330 -> 303 us,
+// 32768 437 -> 412, 65536 680 -> 690 (profiles/r03_ab_midsize_thresholds.txt).
 #ifndef KY_SIDE_MAX_N
-#define KY_SIDE_MAX_N 8192  // tools/build_variant.sh noside -DKY_SIDE_MAX_N=0: the A/B of this path
+#define KY_SIDE_MAX_N 32768  // tools/build_variant.sh noside -DKY_SIDE_MAX_N=0: the A/B of this path
 #endif
 constexpr size_t SIDE_MAX_N = KY_SIDE_MAX_N;
 struct Side {

@@ -104,11 +104,11 @@ def test_multi_device_rejects_absent_device():
 
 
 @pytest.mark.parametrize("n90", [0, 1])
-@pytest.mark.parametrize("n", [1, 300, 2048, 8192, 8193, 16384, 16385])
+@pytest.mark.parametrize("n", [1, 300, 2048, 32768, 32769])
 def test_small_batch_paths_on_user_streams(oracle, n, n90):
     """Small batches take their own routes through the library (kyber_hip.hip): host calls up to 1 MiB go
-    through the pinned mirror on one stream, encapsulations up to 8192 instances expand the matrix on a
-    second stream beside the hashes, and up to 16384 instances the SHAKE-family
+    through the pinned mirror on one stream, encapsulations up to 32768 instances expand the matrix on a
+    second stream beside the hashes, and up to 32768 instances the SHAKE-family
     FO hashes run on work-item pairs (keccak_split.h).  Device-pointer calls on two user
     streams in turn, host calls in between: every byte must be the oracle's, on both sides of the
     thresholds, and calls queued back to back on different streams must not disturb each other."""

@@ -4,10 +4,12 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 import kyber_amd
 kem = kyber_amd.KyberHip(3, 0)
-for use_stream in (False, True):
+import os
+SIZES = tuple(int(x) for x in os.environ.get("KY_LAT_SIZES", "1,256,4096").split(","))
+for use_stream in ((False, True) if "KY_LAT_SIZES" not in os.environ else (False,)):
     st = torch.cuda.Stream() if use_stream else torch.cuda.current_stream()
     with torch.cuda.stream(st):
-        for n in (1, 256, 4096):
+        for n in SIZES:
             g = torch.Generator(device="cuda"); g.manual_seed(n)
             kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
             ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
