@@ -119,15 +119,30 @@ __device__ __forceinline__ void f_twiddles_to_lds(float* Z) {
 }
 
 // ---------------------------------------------------------------- butterflies
+// z * b mod q as three FMAs (wpoly.h's fmulc; -DKY_FMULC=1 builds the 32-lane engine on it for A/Bs):
+// k' = fma(b, z/q, M), m = fma(k', -q, q M) = -q rint(b z / q), r = fma(z, b, m).  Same bound as fmm
+// (|z b| < 2^24), |r| <= 1665.
+#ifndef KY_FMULC
+#define KY_FMULC 0
+#endif
+__device__ __forceinline__ float fmm_c(float z, float b) {
+#if KY_FMULC
+  const float k = __builtin_fmaf(b, z * QINVF, RND_MAGIC);
+  const float m = __builtin_fmaf(k, -QF, QF * RND_MAGIC);
+  return __builtin_fmaf(z, b, m);
+#else
+  return fmm(z, b);
+#endif
+}
 __device__ __forceinline__ void f_ct(float& a, float& b, float z) {  // Cooley-Tukey, ref/ntt.c:89-91
-  float t = fmm(z, b);
+  float t = fmm_c(z, b);
   b = a - t;
   a = a + t;
 }
 __device__ __forceinline__ void f_gs(float& a, float& b, float z) {  // Gentleman-Sande, ref/ntt.c:116-119 (sum left unreduced)
   float t = a;
   a = t + b;
-  b = fmm(z, b - t);
+  b = fmm_c(z, b - t);
 }
 
 // ---------------------------------------------------------------- forward NTT
