@@ -143,3 +143,39 @@ def test_small_batch_paths_on_user_streams(oracle, n, n90):
         hct, hss = kem.enc(opk, ec)
         assert np.array_equal(hct, oct_) and np.array_equal(hss, oss)
         assert np.array_equal(kem.dec(hct, osk), oss)
+
+
+@pytest.mark.parametrize("n90", [0, 1])
+def test_workspace_calls_in_a_captured_graph(oracle, n90):
+    """kyber_batch_enc_dev / dec_dev under stream capture (torch.cuda.CUDAGraph): once the workspace has its size
+    (a call of the same batch size outside capture), a captured encapsulation + decapsulation replays with
+    the oracle's bytes every time, with eager calls in between.  (The second stream of small encapsulations
+    is not used under capture; a captured call that had to GROW the workspace fails instead: no hipMalloc there.)"""
+    import torch
+    k, n = 3, 100
+    kem = kyber_amd.KyberHip(k, n90)
+    kc, ec = _coins(n, 64, 7001), _coins(n, 32, 7002)
+    opk, osk = oracle.keypair(k, kc, n90)
+    oct_, oss = oracle.enc(k, opk, ec, n90)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pk, sk, dec = dev(opk), dev(osk), dev(ec)
+    kem.dec_dev(kem.enc_dev(pk, dec)[0], sk)  # warm: workspace sized for n
+    torch.cuda.synchronize()
+    ct, ss, ssd = (torch.zeros((n, kem.ct_bytes), dtype=torch.uint8, device="cuda"), torch.zeros((n, 32), dtype=torch.uint8, device="cuda"),
+                   torch.zeros((n, 32), dtype=torch.uint8, device="cuda"))
+    side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            kem.enc_dev(pk, dec, ct, ss)
+            kem.dec_dev(ct, sk, ssd)
+    torch.cuda.synchronize()
+    assert not bool(ss.any())  # capture records, it does not run
+    for _ in range(3):
+        ct.zero_(); ss.zero_(); ssd.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(ct.cpu().numpy(), oct_) and np.array_equal(ss.cpu().numpy(), oss) and np.array_equal(ssd.cpu().numpy(), oss)
+        c2, s2 = kem.enc_dev(pk, dec)  # an eager call between replays
+        torch.cuda.synchronize()
+        assert np.array_equal(c2.cpu().numpy(), oct_) and np.array_equal(s2.cpu().numpy(), oss)
