@@ -1265,8 +1265,18 @@ size_t kyber_hip_pk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)384 * k
 size_t kyber_hip_sk_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)768 * k + 96; }
 size_t kyber_hip_ct_bytes(int k) { return (k < 2 || k > 4) ? 0 : (size_t)32 * ((k == 4 ? 11 : 10) * k + (k == 4 ? 5 : 4)); }
 
+// device pointers of the KEM objects: 16-byte aligned (include/kyber_batch.h); the kernels move them as 16-byte pieces
+static bool dev_aligned(std::initializer_list<const void*> ps) {
+  for (const void* p : ps)
+    if (reinterpret_cast<uintptr_t>(p) & 15u) {
+      snprintf(g_err, sizeof g_err, "device pointer %p is not 16-byte aligned", p);
+      return false;
+    }
+  return true;
+}
 int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, void* stream) {
   if (!pk || !sk || !coins) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({pk, sk, coins})) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, keypair_dev, n, pk, sk, coins, st);
@@ -1274,6 +1284,7 @@ int kyber_batch_keypair_dev(int k, int nineties, size_t n, uint8_t* pk, uint8_t*
 int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
                         void* stream) {
   if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ct, ss, pk, coins})) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, enc_each_dev, n, ct, ss, pk, coins, st);
@@ -1281,18 +1292,21 @@ int kyber_batch_enc_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss,
 int kyber_batch_enc_shared_pk_dev(int k, int nineties, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, const uint8_t* coins,
                                   void* stream) {
   if (!ct || !ss || !pk || !coins) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ct, ss, pk, coins})) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, enc_shared_dev, n, ct, ss, pk, coins, st);
 }
 int kyber_batch_dec_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ss, ct, sk})) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : kyber_hip_supported(k, nineties) ? 0 : KYBER_HIP_ENOSYS;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, dec_each_dev, n, ss, ct, sk, st);
 }
 int kyber_batch_dec_dev_noalloc(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ss, ct, sk})) return KYBER_HIP_EINVAL;
   if (k < 2 || k > 4 || (nineties != 0 && nineties != 1)) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1301,6 +1315,7 @@ int kyber_batch_dec_dev_noalloc(int k, int nineties, size_t n, uint8_t* ss, cons
 size_t kyber_hip_noalloc_max_n(void) { return NOALLOC_MAX_N; }
 int kyber_batch_dec_shared_sk_dev(int k, int nineties, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, void* stream) {
   if (!ss || !ct || !sk) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ss, ct, sk})) return KYBER_HIP_EINVAL;
   if (n == 0) return (k < 2 || k > 4) ? KYBER_HIP_EINVAL : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH(k, nineties, dec_shared_dev, n, ss, ct, sk, st);
@@ -1359,12 +1374,14 @@ int kyber_hip_prepared_free(kyber_hip_prepared* h) {
 }
 int kyber_batch_enc_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* coins, void* stream) {
   if (!ct || !ss || !coins) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ct, ss, coins})) return KYBER_HIP_EINVAL;
   if (int rc = prepared_check(h, 0)) return rc;
   if (n == 0) return 0;
   DISPATCH(h->k, h->n90, enc_prepared_dev, h, n, ct, ss, coins, static_cast<hipStream_t>(stream));
 }
 int kyber_batch_dec_prepared_dev(const kyber_hip_prepared* h, size_t n, uint8_t* ss, const uint8_t* ct, void* stream) {
   if (!ss || !ct) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ss, ct})) return KYBER_HIP_EINVAL;
   if (int rc = prepared_check(h, 1)) return rc;
   if (n == 0) return 0;
   DISPATCH(h->k, h->n90, dec_prepared_dev, h, n, ss, ct, static_cast<hipStream_t>(stream));

@@ -68,6 +68,16 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.kyber_batch_keypair(7, 0, 1, buf, buf, buf) == -1          # bad k
     assert lib.kyber_batch_enc(3, 0, 1, None, buf, buf, buf) == -1         # NULL output
     assert lib.kyber_batch_dec_dev(3, 0, 1, buf, None, buf, None) == -1
+    # device pointers are 16-byte aligned (include/kyber_batch.h): refused before anything touches a GPU
+    import ctypes as _ct
+    base = _ct.addressof(buf)
+    base += (-base) % 16
+    al, mis = _ct.c_void_p(base), _ct.c_void_p(base + 8)
+    assert lib.kyber_batch_dec_dev(3, 0, 1, al, mis, al, None) == -1
+    assert b"16-byte aligned" in lib.kyber_hip_last_error()
+    assert lib.kyber_batch_enc_dev(3, 0, 1, al, al, al, mis, None) == -1
+    assert lib.kyber_batch_keypair_dev(3, 0, 1, mis, al, al, None) == -1
+    assert lib.kyber_batch_dec_dev_noalloc(3, 0, 1, al, al, mis, None) == -1
     assert lib.kyber_batch_keypair(3, 0, 0, buf, buf, buf) == 0            # empty batch is a no-op
     assert lib.kyber_batch_enc(4, 0, 0, buf, buf, buf, None) == 0
 

@@ -4,6 +4,8 @@
 # counter passes (tools/pmc_all.sh).  Outputs land in gpurun_out/<rNN>_*; tools/round_profiles_collect.py
 # copies the summaries into profiles/.
 # A third argument selects a part (a gpurun call is limited to 20 minutes): bench | pmc | all (default).
+# After a change of the library run `pmc` first, collect (tools/round_profiles_collect.py), THEN `bench` in a call of its own:
+# bench.py reads the counter traffic from profiles/*_pmc_traffic*.json and drops a figure recorded for another build.
 set -e
 R=$1
 PART=${2:-all}
