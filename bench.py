@@ -520,7 +520,19 @@ def main():
     if world > 1 or "RANK" in os.environ:  # under torchrun, also with one rank, so the RCCL path can be rehearsed on one GPU
         import torch.distributed as dist
         kw = {"device_id": dev} if backend == "nccl" else {}
-        dist.init_process_group(backend, **kw)
+        # RCCL announces itself on STDOUT when its communicator comes up ("HIP version : ...", "Librccl path : ..."):
+        # stdout carries the one JSON line and nothing else, so the file descriptor points at stderr until
+        # the communicator exists (init + a first barrier).
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, **kw)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def sync():
         if on_gpu:
