@@ -4,6 +4,7 @@ ref) on millions of random instances per parameter set, every byte compared.
 Test infrastructure (uses oracle_lib.py beside it), run by hand, not collected by pytest.
 
     python3 tests/soak.py [seconds per set = 60] [batch = 2^19]
+    python3 tests/soak.py 40 -40000      # a negative batch: every round draws its size from [1, 40000] (the small-batch routes)
 """
 import os
 import sys
@@ -19,7 +20,7 @@ import kyber_amd  # noqa: E402
 import oracle_lib  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19
+nmax = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19
 threads = 16
 for k in (3, 2, 4):
     for n90 in (0, 1):
@@ -29,6 +30,7 @@ for k in (3, 2, 4):
         rng = np.random.default_rng(1_000_003 * k + n90)
         t0, total, rounds = time.time(), 0, 0
         while time.time() - t0 < budget:
+            n = nmax if nmax > 0 else int(rng.integers(1, -nmax + 1))
             kc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
             ec = rng.integers(0, 256, (n, 32), dtype=np.uint8)
             pk, sk = kem.keypair(kc)
@@ -45,8 +47,8 @@ for k in (3, 2, 4):
                 rct[lo:hi], rss[lo:hi] = ref.enc(rpk[lo:hi], ec[lo:hi])
                 rdec[lo:hi] = ref.dec(bad[lo:hi], rsk[lo:hi])
 
-            b = np.linspace(0, n, threads + 1).astype(int)
-            ths = [threading.Thread(target=work, args=(b[i], b[i + 1])) for i in range(threads)]
+            b = np.linspace(0, n, min(threads, n) + 1).astype(int)
+            ths = [threading.Thread(target=work, args=(b[i], b[i + 1])) for i in range(len(b) - 1)]
             for t in ths:
                 t.start()
             for t in ths:
@@ -59,5 +61,7 @@ for k in (3, 2, 4):
                     sys.exit(1)
             total += n
             rounds += 1
-            print("Kyber%d%s: %d instances identical to %s (%.0f s)" % (256 * k, "-90s" if n90 else "", total, impl, time.time() - t0), flush=True)
+            if nmax > 0 or rounds % 50 == 0:
+                print("Kyber%d%s: %d instances identical to %s (%.0f s, %d rounds)" % (256 * k, "-90s" if n90 else "", total, impl, time.time() - t0, rounds), flush=True)
+        print("Kyber%d%s: done, %d instances in %d rounds identical to %s" % (256 * k, "-90s" if n90 else "", total, rounds, impl), flush=True)
 print("soak ok")
