@@ -323,3 +323,31 @@ def test_wide_engine_products_and_reductions_are_exact():
     for z in (512, -266, -26, 1652, 1664, -1664):
         r = fmulc_canon(bb.astype(f32), z).astype(np.int64)
         assert np.array_equal(r, np.mod(z * bb, Q)), z
+
+
+def test_pair_rotation_identity_of_keccak_split():
+    """kyber_amd/csrc/keccak_split.h: with the low halves of the 25 lanes on one work-item and the high halves on
+    its partner, a 64-bit rotate by N is own' = alignbit(own, other, 32 - N) for N < 32, `other` for N = 32 and
+    alignbit(other, own, 64 - N) for N > 32 -- the same instruction on both work-items.  Checked here for every
+    rho offset of Keccak-f[1600] and the theta rotate on random words (v_alignbit_b32: (hi:lo) >> s, low 32 bits)."""
+    def alignbit(hi, lo, s):
+        return ((hi << 32 | lo) >> s) & 0xFFFFFFFF
+
+    def half(own, oth, n):
+        if n == 0:
+            return own
+        if n == 32:
+            return oth
+        return alignbit(own, oth, 32 - n) if n < 32 else alignbit(oth, own, 64 - n)
+
+    offsets, x, y = {0, 1}, 1, 0
+    for t in range(24):
+        offsets.add(((t + 1) * (t + 2) // 2) % 64)
+        x, y = y, (2 * x + 3 * y) % 5
+    assert len(offsets) == 25 and max(offsets) == 62
+    rng = np.random.default_rng(64)
+    for n in sorted(offsets):
+        for v in [int(w) for w in rng.integers(0, 1 << 63, 50, dtype=np.uint64)] + [1, 1 << 63, (1 << 64) - 1]:
+            lo, hi = v & 0xFFFFFFFF, v >> 32
+            want = ((v << n) | (v >> (64 - n))) & ((1 << 64) - 1) if n else v
+            assert half(lo, hi, n) == want & 0xFFFFFFFF and half(hi, lo, n) == want >> 32, n
