@@ -126,6 +126,11 @@ def kernel_work(name, k, n90, shared=False):
         "k_kp_arith": (2 * k * NTT_LANE_OPS + k * k * BASEMUL_LANE_OPS, k * k * 512 + prf_bytes(2 * k, 0) + pkb + skb),
     }
     t["k_enc_arith_cmp"] = t["k_enc_arith"]
+    # batches of up to 65536 instances (keccak_split.h): two independent stages in one launch
+    add = lambda a, b: (t[a][0] + t[b][0], t[a][1] + t[b][1])
+    t["k_enc_front"] = add("k_enc_pre", "k_sample_matrix")
+    kp_prf = ((2 if k == 2 else 1) * 2 * k * P, 32 + prf_bytes(2 * k, 0))   # 2K noise polynomials, all eta1
+    t["k_kp_front"] = (t["k_sample_matrix"][0] + kp_prf[0], t["k_sample_matrix"][1] + kp_prf[1])
     if shared and name in ("k_sample_matrix", "k90_sample_matrix"):  # one expansion per call, not per instance
         return None
     return t.get(name)

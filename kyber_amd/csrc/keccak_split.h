@@ -18,8 +18,7 @@
 // Same functions restated as keccak.h / kem_kernels.h: ref/fips202.c:82-344, :461-485, :745-774;
 // ref/kem.c:23-127 (the hashes around the IND-CPA core).
 #pragma once
-#include "keccak.h"
-#include "params.h"
+#include "kem_kernels.h"
 
 namespace ky {
 
@@ -194,10 +193,13 @@ __global__ void __launch_bounds__(SPLIT_WG) k2_hash_pk(const uint8_t* __restrict
   ks_st32B(out, h, A[0], A[1], A[2], A[3]);
 }
 
+// encaps, before (k_enc_pre of kem_kernels.h) for work-item g of the pairs: instance g >> 1, half g & 1
 template <class P>
-__global__ void __launch_bounds__(SPLIT_WG) k2_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
-                                                       const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
-  KS_PROLOGUE(n);
+__device__ __forceinline__ void ks_enc_pre_body(int g, int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
+  const int i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
   uint32_t A[25], m[4], hp[4];
   ks_ld32B(coins + (size_t)i * 32, h, m);
   ks_sha3_256_32(A, m, h);
@@ -215,6 +217,44 @@ __global__ void __launch_bounds__(SPLIT_WG) k2_enc_pre(int n, const uint8_t* __r
   ks_st32B(s, h, m[0], m[1], m[2], m[3]);
   ks_st32B(s + 32, h, A[0], A[1], A[2], A[3]);
   ks_st32B(s + 64, h, A[4], A[5], A[6], A[7]);
+}
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG) k2_enc_pre(int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                       const uint8_t* __restrict__ hpk, uint8_t* __restrict__ small) {
+  ks_enc_pre_body<P>(blockIdx.x * SPLIT_WG + threadIdx.x, n, coins, pk, hpk, small);
+}
+
+// ------------------------------------------------------------------ front kernels of small batches
+// Up to FRONT_MAX_N instances no kernel fills the chip for long and a call is the sum of its dependent launches, each as
+// long as its slowest lane.  Two pairs of neighbours in those chains do not depend on each other -- in an
+// encapsulation the hashes in front (H(m), H(pk), G: eleven permutations) and the matrix expansion (three, from rho
+// alone); in a key generation the matrix expansion and the PRF (both from G(d)) -- so each pair is ONE launch whose
+// first workgroups do the one job and the rest the other, every workgroup a single wavefront.  They run side by
+// side on the idle chip: the shorter job and one launch gap disappear from the chain, without a second stream.
+// Threshold by same-box A/B on device-pointer calls (profiles/r03_ab_latency_front_kernels.txt): keypair / enc at n = 1
+// 152 / 219 -> 134 / 183 us, 8192: 195 / 252 -> 178 / 198, 16384: 262 / 310 -> 215 / 243, 65536: 605 / 688 -> 573 / 643,
+// 131072 a tie, 262144 +1 / +4 %: there the matrix kernel wants its 512-lane workgroups and phase lock back (keccak.h).
+#ifndef KY_FRONT_MAX_N
+#define KY_FRONT_MAX_N 65536
+#endif
+constexpr size_t FRONT_MAX_N = KY_FRONT_MAX_N;
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG, 4) k_enc_front(int n, int nb_pre, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                           size_t pk_stride_rho, uint8_t* __restrict__ small, int16_t* __restrict__ mat,
+                                                           uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+  static_assert(SPLIT_WG == SPONGE_WG_SMALL, "one wavefront per workgroup in both jobs");
+  if ((int)blockIdx.x < nb_pre)
+    ks_enc_pre_body<P>(blockIdx.x * SPLIT_WG + threadIdx.x, n, coins, pk, nullptr, small);
+  else  // A^T from the rho of every public key (ref/indcpa.c:270)
+    sample_matrix_body<P, SPONGE_WG_SMALL, 0>(blockIdx.x - nb_pre, n * P::NMAT, pk + P::PVB, pk_stride_rho, 1, mat, tailq, tail_cap);
+}
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG, 4) k_kp_front(int n, int nb_mat, uint8_t* __restrict__ small, int16_t* __restrict__ mat,
+                                                          uint32_t* __restrict__ tailq, uint32_t tail_cap, uint8_t* __restrict__ prf) {
+  if ((int)blockIdx.x < nb_mat)  // A from rho = G(d)[0..31] (ref/indcpa.c:219)
+    sample_matrix_body<P, SPONGE_WG_SMALL, 0>(blockIdx.x, n * P::NMAT, small, SMALL, 0, mat, tailq, tail_cap);
+  else  // s, e from sigma = G(d)[32..63], nonces 0..2K-1 (ref/indcpa.c:220-223)
+    prf_body<P>((long)(blockIdx.x - nb_mat) * SPLIT_WG + threadIdx.x, n, 2 * P::K, 2 * P::K, small, 32, prf);
 }
 
 template <class P>

@@ -286,10 +286,10 @@ __global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_check(int n, const uint8_t*
 // uniform in the output length.  Writes the raw PRF bytes; the centred
 // binomial map is applied by the consumer in poly layout.
 // ref/symmetric-shake.c:43-51 + ref/poly.c:208-232 (prf part).
+// (a device function: k_prf runs it on its own, k_kp_front beside the matrix expansion)
 template <class P>
-__global__ void __launch_bounds__(SPONGE_WG, 4) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
-                                             int seed_off, uint8_t* __restrict__ prf) {
-  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prf_body(long gid, int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+                                         int seed_off, uint8_t* __restrict__ prf) {
   if (gid >= (long)n * njobs_per_inst) return;
   int nonce = (int)(gid / n), inst = (int)(gid % n);
   u64p A[25], key[4];
@@ -313,6 +313,11 @@ __global__ void __launch_bounds__(SPONGE_WG, 4) k_prf(int n, int njobs_per_inst,
         *reinterpret_cast<uint4*>(out + 136 + 8 * (w - 1) + 8) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
     }
   }
+}
+template <class P>
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_prf(int n, int njobs_per_inst, int n_eta1, const uint8_t* __restrict__ small,
+                                             int seed_off, uint8_t* __restrict__ prf) {
+  prf_body<P>((long)blockIdx.x * blockDim.x + threadIdx.x, n, njobs_per_inst, n_eta1, small, seed_off, prf);
 }
 
 // ------------------------------------------------------------------ matrix expansion
@@ -443,12 +448,14 @@ __device__ __forceinline__ void tail_parse(const uint32_t (&H)[42], int16_t* out
 // stores at cursor-independent, conflict-free addresses; 4: no drain, no staging stores)
 // WG = lanes per workgroup: SPONGE_WG, or SPONGE_WG_SMALL for launches that cannot fill the chip
 // (keccak.h); the staging tile is sized by it.
-template <class P, int WG = SPONGE_WG, int ABLATE = 0>
-__global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
-                                                                   int transposed, int16_t* __restrict__ mat,
-                                                                   uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+// (a device function over a block index: k_sample_matrix runs it on its own, k_enc_front / k_kp_front as some of their
+// workgroups beside the hashes / the PRF of small batches)
+template <class P, int WG, int ABLATE>
+__device__ __forceinline__ void sample_matrix_body(unsigned bid, int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                   int transposed, int16_t* __restrict__ mat,
+                                                   uint32_t* __restrict__ tailq, uint32_t tail_cap) {
   __shared__ uint32_t stage[WG * MAT_STAGE_DW + 8];  // the last lane's remainder move may read 8 dwords past its row
-  const long job = (long)blockIdx.x * WG + threadIdx.x;
+  const long job = (long)bid * WG + threadIdx.x;
   const bool valid = job < njobs;
   const long jc = valid ? job : (long)njobs - 1;
   const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
@@ -529,6 +536,13 @@ __global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_
       }
     }
   }
+}
+
+template <class P, int WG = SPONGE_WG, int ABLATE = 0>
+__global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                                   int transposed, int16_t* __restrict__ mat,
+                                                                   uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+  sample_matrix_body<P, WG, ABLATE>(blockIdx.x, njobs, rho, rho_stride, transposed, mat, tailq, tail_cap);
 }
 
 // Finishes the entries parked by k_sample_matrix: one work-item per queue

@@ -257,6 +257,26 @@ int sample_matrix(int entries, const uint8_t* rho, size_t rho_stride, int transp
   if (tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(tail_cap, 64), 64, 0, st>>>(tailq, tail_cap, mat));
   return 0;
 }
+// small batches (keccak_split.h, "front kernels"): the matrix expansion as some of the workgroups of one launch
+// that also runs the hashes in front of an encapsulation / the PRF of a key generation
+template <class P>
+int enc_front(int m, const uint8_t* coins, const uint8_t* pk, Layout<P>& L, hipStream_t st) {
+  k_zero32<<<1, 64, 0, st>>>(L.tailq);
+  LAUNCH_CHECK("k_zero32");
+  const unsigned nb_pre = blocks(2 * (size_t)m, SPLIT_WG), nb_mat = blocks((size_t)m * P::NMAT, SPONGE_WG_SMALL);
+  RUN("k_enc_front", st, k_enc_front<P><<<nb_pre + nb_mat, SPLIT_WG, 0, st>>>(m, (int)nb_pre, coins, pk, P::PKB, L.small, L.mat, L.tailq, L.tail_cap));
+  if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+  return 0;
+}
+template <class P>
+int kp_front(int m, Layout<P>& L, hipStream_t st) {
+  k_zero32<<<1, 64, 0, st>>>(L.tailq);
+  LAUNCH_CHECK("k_zero32");
+  const unsigned nb_mat = blocks((size_t)m * P::NMAT, SPONGE_WG_SMALL), nb_prf = blocks((size_t)m * 2 * P::K, SPLIT_WG);
+  RUN("k_kp_front", st, k_kp_front<P><<<nb_mat + nb_prf, SPLIT_WG, 0, st>>>(m, (int)nb_mat, L.small, L.mat, L.tailq, L.tail_cap, L.prf));
+  if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+  return 0;
+}
 
 // Matrix expansion for `insts` instances (SHAKE128 or AES-256-CTR XOF), Aᵀ when transposed.
 template <class P, bool N90>
@@ -371,10 +391,13 @@ int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStr
     uint8_t *p = pk + o * P::PKB, *s = sk + o * P::SKB;
     if constexpr (N90) RUN("k90_kp_pre", st, k90_kp_pre<<<blocks(m, 256), 256, 0, st>>>(m, c, L.small));
     else RUN_HASH("k_kp_pre", st, m, k_kp_pre, k2_kp_pre, m, c, L.small);
-    if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
     if constexpr (N90) {
+      if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * 2 * P::K, (m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    } else if ((size_t)m <= FRONT_MAX_N) {
+      if (int rc = kp_front<P>(m, L, st)) return rc;
     } else {
+      if (int rc = expand_matrix<P, N90>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
       RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
     }
     RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
@@ -404,7 +427,8 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
   const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  Side* sd = side_for(n, st);
+  const bool front = !N90 && !shared && n <= FRONT_MAX_N;  // one launch for the hashes in front and the matrix expansion
+  Side* sd = front ? nullptr : side_for(n, st);
   bool pending = false;
   if (shared && !pmat) {
     if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
@@ -418,10 +442,12 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = pk + o * pk_stride;
     uint8_t* c = ct + o * P::CTB;
-    if (!shared)
+    if (!shared && !front)
       if (int rc = expand_matrix_beside<P, N90>(sd, &pending, m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       RUN("k90_enc_pre", st, k90_enc_pre<P><<<blocks(m, 256), 256, 0, st>>>(m, coins + o * 32, p, hpk, L.small));
+    } else if (front) {
+      if (int rc = enc_front<P>(m, coins + o * 32, p, L, st)) return rc;
     } else {
       RUN_HASH("k_enc_pre", st, m, k_enc_pre<P>, k2_enc_pre<P>, m, coins + o * 32, p, hpk, L.small);
     }

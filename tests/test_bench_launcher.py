@@ -86,9 +86,9 @@ def test_two_ranks_on_one_gpu_rehearsal():
     RCCL refuses two ranks on one device); the HIP engine runs in both."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "65536",
-           "--ranks-share-device", "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--ranks-share-device", "--dist-backend", "gloo", "--no-cpu-baseline"]  # 65536: encapsulation's front stages are one launch
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["parity"]["ss_dec_equals_ss_enc"] is True
-    assert d["roofline"]["kernel"] == "k_sample_matrix"
+    assert d["roofline"]["kernel"] in ("k_sample_matrix", "k_enc_front") and 0 < d["roofline"]["frac"] <= 1

@@ -108,7 +108,8 @@ def test_multi_device_rejects_absent_device():
 def test_small_batch_paths_on_user_streams(oracle, n, n90):
     """Small batches take their own routes through the library (kyber_hip.hip): host calls up to 1 MiB go
     through the pinned mirror on one stream, encapsulations up to 32768 instances expand the matrix on a
-    second stream beside the hashes, and up to 32768 instances the SHAKE-family
+    second stream beside the hashes (SHAKE sets up to 65536: in the same launch as the hashes, k_enc_front; key generation runs
+    its matrix expansion and PRF as one launch, k_kp_front), and up to 32768 instances the SHAKE-family
     FO hashes run on work-item pairs (keccak_split.h).  Device-pointer calls on two user
     streams in turn, host calls in between: every byte must be the oracle's, on both sides of the
     thresholds, and calls queued back to back on different streams must not disturb each other."""
@@ -179,3 +180,26 @@ def test_workspace_calls_in_a_captured_graph(oracle, n90):
         c2, s2 = kem.enc_dev(pk, dec)  # an eager call between replays
         torch.cuda.synchronize()
         assert np.array_equal(c2.cpu().numpy(), oct_) and np.array_equal(s2.cpu().numpy(), oss)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_front_kernels_agree_with_the_separate_launches(k):
+    """Up to 65536 instances key generation and encapsulation run their independent front stages as one launch
+    (k_kp_front, k_enc_front); one instance more and they are the separate kernels of large batches.  The same
+    65536 inputs through both: every byte equal (the large-batch path is pinned by the oracle, the vectors and
+    the soak)."""
+    import torch
+    n = 65536
+    kem = kyber_amd.KyberHip(k)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6500 + k)
+    kc = torch.randint(0, 256, (n + 1, 64), dtype=torch.uint8, device="cuda", generator=g)
+    ec = torch.randint(0, 256, (n + 1, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk_big, sk_big = kem.keypair_dev(kc)
+    ct_big, ss_big = kem.enc_dev(pk_big, ec)
+    pk, sk = kem.keypair_dev(kc[:n])
+    ct, ss = kem.enc_dev(pk, ec[:n])
+    torch.cuda.synchronize()
+    assert torch.equal(pk, pk_big[:n]) and torch.equal(sk, sk_big[:n])
+    assert torch.equal(ct, ct_big[:n]) and torch.equal(ss, ss_big[:n])
+    assert torch.equal(kem.dec_dev(ct, sk), ss)
