@@ -131,6 +131,8 @@ def kernel_work(name, k, n90, shared=False):
     t["k_enc_front"] = add("k_enc_pre", "k_sample_matrix")
     kp_prf = ((2 if k == 2 else 1) * 2 * k * P, 32 + prf_bytes(2 * k, 0))   # 2K noise polynomials, all eta1
     t["k_kp_front"] = (t["k_sample_matrix"][0] + kp_prf[0], t["k_sample_matrix"][1] + kp_prf[1])
+    t["k_dec_middle"] = (t["k_sample_matrix"][0] + (h(ctb) + 1) * P, t["k_sample_matrix"][1] + ctb + 32 + 128)  # + H(ct) + G
+    t["k_kdf_dec"] = (1 * P, 64 + 32 + 32)
     if shared and name in ("k_sample_matrix", "k90_sample_matrix"):  # one expansion per call, not per instance
         return None
     return t.get(name)

@@ -354,17 +354,16 @@ __global__ void __launch_bounds__(256, P::K <= 3 ? 4 : 3) k_enc_arith(int n, con
 // same-box A/B 0.495 -> 0.471 ms per 2^19 against 16-bit loads); s^ arrives as
 // 12 key bytes per work-item and polynomial.
 // (72 VGPRs for K = 3: seven wavefronts per SIMD; a bound of eight spills)
-// (a device function over a block index: k_dec_arith runs it on its own, k_dec_front of dec_front.h as some of its workgroups)
 template <class P>
-__device__ __forceinline__ void dec_arith_body(unsigned bid, int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
-                                               size_t sk_stride, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
+                                                   size_t sk_stride, uint8_t* __restrict__ small) {
   constexpr int K = P::K, CT16 = P::CTB / 16;
   using G = FcGroups<K>;
   __shared__ __attribute__((aligned(16))) uint8_t ctb[G_INST][P::CTB];
   __shared__ __attribute__((aligned(16))) float wk[8][256];
   __shared__ float ztab[128];
   const Grp w = grp();
-  const int inst0 = (int)bid * G_INST;
+  const int inst0 = blockIdx.x * G_INST;
   const int li = w.g;
   const int gi = min(inst0 + li, n - 1);
   const uint8_t* sk_i = sk + (size_t)gi * sk_stride;
@@ -412,11 +411,6 @@ __device__ __forceinline__ void dec_arith_body(unsigned bid, int n, const uint8_
 #pragma unroll
   for (int k = 0; k < 8; k++) byte |= fcompress<1>((float)v[k] - acc[k]) << k;  // |.| <= 3328 + 1668
   if (inst0 + li < n) small[(size_t)gi * SMALL + w.t] = (uint8_t)byte;
-}
-template <class P>
-__global__ void __launch_bounds__(256) k_dec_arith(int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk,
-                                                   size_t sk_stride, uint8_t* __restrict__ small) {
-  dec_arith_body<P>(blockIdx.x, n, ct, sk, sk_stride, small);
 }
 
 // ------------------------------------------------------------------ standalone polynomial kernels

@@ -17,10 +17,6 @@ void launch_enc_arith(hipStream_t st, int n, const uint8_t* pk, size_t pk_stride
                       size_t mat_stride, const uint8_t* prf, uint8_t* ct);
 template <class P>
 void launch_dec_arith(hipStream_t st, int n, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, uint8_t* small);
-// small batches (dec_front.h): the decryption arithmetic and the expansion of A^T from the key's rho in one launch
-template <class P>
-void launch_dec_front(hipStream_t st, int n, const uint8_t* ct, const uint8_t* sk, uint8_t* small, int16_t* mat, uint32_t* tailq,
-                      uint32_t tail_cap);
 
 void launch_poly_ntt(hipStream_t st, size_t npoly, int16_t* r);
 void launch_poly_invntt(hipStream_t st, size_t npoly, int16_t* r);

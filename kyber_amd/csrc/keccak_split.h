@@ -257,9 +257,12 @@ __global__ void __launch_bounds__(SPLIT_WG, 4) k_kp_front(int n, int nb_mat, uin
     prf_body<P>((long)(blockIdx.x - nb_mat) * SPLIT_WG + threadIdx.x, n, 2 * P::K, 2 * P::K, small, 32, prf);
 }
 
+// decaps, middle (k_dec_mid of kem_kernels.h) for work-item g of the pairs
 template <class P>
-__global__ void __launch_bounds__(SPLIT_WG) k2_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ small) {
-  KS_PROLOGUE(n);
+__device__ __forceinline__ void ks_dec_mid_body(int g, int n, const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ small) {
+  const int i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
   uint32_t A[25], m[4], hp[4];
   uint8_t* s = small + (size_t)i * SMALL;
   ks_ld32B(s, h, m);
@@ -267,6 +270,10 @@ __global__ void __launch_bounds__(SPLIT_WG) k2_dec_mid(int n, const uint8_t* __r
   ks_sha3_512_64(A, m, hp, h);
   ks_st32B(s + 32, h, A[0], A[1], A[2], A[3]);
   ks_st32B(s + 64, h, A[4], A[5], A[6], A[7]);
+}
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG) k2_dec_mid(int n, const uint8_t* __restrict__ sk, size_t sk_stride, uint8_t* __restrict__ small) {
+  ks_dec_mid_body<P>(blockIdx.x * SPLIT_WG + threadIdx.x, n, sk, sk_stride, small);
 }
 
 template <class P, bool DEC>
@@ -290,5 +297,57 @@ __global__ void __launch_bounds__(SPLIT_WG) k2_post(int n, const uint8_t* __rest
   ks_st32B(ss + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
 }
 #undef KS_PROLOGUE
+
+// ------------------------------------------------------------------ the middle launch of a small decapsulation
+// ss = KDF(Kbar'-or-z || H(ct)) (ref/kem.c:119-125): the nine permutations of H(ct) need nothing but the ciphertext the
+// caller handed in, yet as part of k_post they sit at the END of the chain, behind the re-encryption.  For batches up to
+// FRONT_MAX_N they move forward into ONE launch with the two other jobs that can start once m' is known and do not
+// depend on each other: the matrix expansion (three permutations from the key's rho) and G(m' || H(pk)) (one).  Its first
+// workgroups sample, the next hash ciphertexts on pairs, the last compute G on pairs; H(ct) waits in the caller's ss
+// buffer, and what is left behind the re-encryption is the one permutation of the KDF (k2_kdf_dec).
+template <class P>
+__device__ __forceinline__ void ks_hash_ct_body(int g, int n, const uint8_t* __restrict__ ct, uint8_t* __restrict__ out) {
+  const int i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
+  uint32_t A[25];
+  ks_absorb_words<136, 0x06, P::CTB>(A, ct + (size_t)i * P::CTB, h);
+  ks_st32B(out + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
+}
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG, 4) k_dec_middle(int n, int nb_mat, int nb_h, const uint8_t* __restrict__ sk, int16_t* __restrict__ mat,
+                                                            uint32_t* __restrict__ tailq, uint32_t tail_cap, const uint8_t* __restrict__ ct,
+                                                            uint8_t* __restrict__ ss, uint8_t* __restrict__ small) {
+  const int b = (int)blockIdx.x;
+  if (b < nb_mat)  // A^T from the rho inside the secret key's copy of pk (ref/indcpa.c:270 via ref/kem.c:114)
+    sample_matrix_body<P, SPONGE_WG_SMALL, 0>(blockIdx.x, n * P::NMAT, sk + 2 * P::PVB, P::SKB, 1, mat, tailq, tail_cap);
+  else if (b < nb_mat + nb_h)
+    ks_hash_ct_body<P>((b - nb_mat) * SPLIT_WG + threadIdx.x, n, ct, ss);
+  else  // (Kbar', r') = G(m' || H(pk)), ref/kem.c:109-111
+    ks_dec_mid_body<P>((b - nb_mat - nb_h) * SPLIT_WG + threadIdx.x, n, sk, P::SKB, small);
+}
+// the same hash on its own (one key for the whole batch: no matrix to expand beside it)
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG) k2_hash_ct(int n, const uint8_t* __restrict__ ct, uint8_t* __restrict__ ss) {
+  ks_hash_ct_body<P>(blockIdx.x * SPLIT_WG + threadIdx.x, n, ct, ss);
+}
+// ss holds H(ct) on entry and the shared secret on return; constant-time select as ref/verify.c:40-47
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG) k2_kdf_dec(int n, const uint8_t* __restrict__ small, const uint8_t* __restrict__ sk,
+                                                       size_t sk_stride, uint8_t* __restrict__ ss) {
+  const int g = blockIdx.x * SPLIT_WG + threadIdx.x, i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
+  uint32_t A[25], kb[4], hc[4], z[4];
+  const uint8_t* s = small + (size_t)i * SMALL;
+  ks_ld32B(ss + (size_t)i * 32, h, hc);
+  ks_ld32B(s + 32, h, kb);
+  ks_ld32B(sk + (size_t)i * sk_stride + 2 * P::PVB + 64, h, z);
+  const uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
+#pragma unroll
+  for (int w = 0; w < 4; w++) kb[w] ^= mask & (kb[w] ^ z[w]);
+  ks_shake256_64(A, kb, hc, h);
+  ks_st32B(ss + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
+}
 
 }  // namespace ky

@@ -62,7 +62,7 @@ __device__ __forceinline__ void st32B(uint8_t* p, const u64p& a, const u64p& b, 
 
 // ------------------------------------------------------------------ FO hashes
 // keypair, before: (rho, sigma) = G(d).                        ref/indcpa.c:215-216
-static __global__ void __launch_bounds__(SPONGE_WG, 4) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_kp_pre(int n, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(SPONGE_WG, 4) k_post(int n, const uint8_t* __r
 // (Decaps_internal: implicit rejection key J(z || c) = SHAKE256(z || c, 32)).
 
 // keypair, before: (rho, sigma) = G(d || k)
-static __global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+__global__ void __launch_bounds__(SPONGE_WG, 4) k_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64p d[4], A[25];
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_
 // accepted candidates to the polynomial in place (coefficients below the saved
 // count are already in memory).  ~1 % of the entries, a handful of
 // coefficients each, so the scattered 2-byte stores do not matter.
-static __global__ void __launch_bounds__(64) k_sample_matrix_tail(const uint32_t* __restrict__ tailq, uint32_t tail_cap,
+__global__ void __launch_bounds__(64) k_sample_matrix_tail(const uint32_t* __restrict__ tailq, uint32_t tail_cap,
                                                            int16_t* __restrict__ mat) {
   const uint32_t cnt = min(tailq[0], tail_cap);
   const uint32_t id = blockIdx.x * 64 + threadIdx.x;

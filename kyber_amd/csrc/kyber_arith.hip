@@ -2,7 +2,6 @@
 // arithmetic) kernels and their launchers.  Built with -fno-slp-vectorize, see
 // arith_kernels.h.
 #include "arith_kernels.h"
-#include "dec_front.h"
 #include "wpoly.h"
 #include "arith_launch.h"
 
@@ -23,12 +22,6 @@ template <class P>
 void launch_dec_arith(hipStream_t st, int n, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, uint8_t* small) {
   k_dec_arith<P><<<nblocks(n, G_INST), 256, 0, st>>>(n, ct, sk, sk_stride, small);
 }
-template <class P>
-void launch_dec_front(hipStream_t st, int n, const uint8_t* ct, const uint8_t* sk, uint8_t* small, int16_t* mat, uint32_t* tailq,
-                      uint32_t tail_cap) {
-  const unsigned nb_arith = nblocks(n, G_INST), nb_mat = nblocks((size_t)n * P::NMAT, DEC_FRONT_WG);
-  k_dec_front<P><<<nb_arith + nb_mat, DEC_FRONT_WG, 0, st>>>(n, (int)nb_arith, ct, sk, small, mat, tailq, tail_cap);
-}
 
 #define KY_INSTANTIATE(KK)                                                                                            \
   template void launch_kp_arith<Par<KK>>(hipStream_t, int, const uint8_t*, const int16_t*, const uint8_t*, uint8_t*, uint8_t*); \
@@ -36,8 +29,7 @@ void launch_dec_front(hipStream_t st, int n, const uint8_t* ct, const uint8_t* s
                                                  const uint8_t*, uint8_t*);                                           \
   template void launch_enc_arith<Par<KK>, true>(hipStream_t, int, const uint8_t*, size_t, uint8_t*, const int16_t*, size_t,     \
                                                 const uint8_t*, uint8_t*);                                            \
-  template void launch_dec_arith<Par<KK>>(hipStream_t, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);     \
-  template void launch_dec_front<Par<KK>>(hipStream_t, int, const uint8_t*, const uint8_t*, uint8_t*, int16_t*, uint32_t*, uint32_t);
+  template void launch_dec_arith<Par<KK>>(hipStream_t, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 KY_INSTANTIATE(2)
 KY_INSTANTIATE(3)
 KY_INSTANTIATE(4)

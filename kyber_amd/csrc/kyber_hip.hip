@@ -307,7 +307,6 @@ int expand_matrix(int insts, const uint8_t* rho, size_t rho_stride, int transpos
 #define KY_SIDE_MAX_N 32768  // tools/build_variant.sh noside -DKY_SIDE_MAX_N=0: the A/B of this path
 #endif
 constexpr size_t SIDE_MAX_N = KY_SIDE_MAX_N;
-constexpr size_t DEC_FRONT_MIN_N = 8192;
 struct Side {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -483,24 +482,29 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = sk + o * sk_stride;
-    // decryption and matrix expansion as one launch (dec_front.h).  Same-box A/B (profiles/r03_ab_latency_front_kernels.txt):
-    // n = 16384 284 -> 263 us, 65536 675 -> 655; up to 4096 the decryption is too short to matter (+-1 %), so from 8192 on.
-    const bool front = !N90 && !shared && (size_t)m <= FRONT_MAX_N && (size_t)m >= DEC_FRONT_MIN_N;
-    if (front) {
-      k_zero32<<<1, 64, 0, st>>>(L.tailq);
-      LAUNCH_CHECK("k_zero32");
-      RUN("k_dec_front", st, launch_dec_front<P>(st, m, c, s, L.small, L.mat, L.tailq, L.tail_cap));
-      if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+    // Batches up to FRONT_MAX_N (SHAKE sets, a key per instance): the three jobs between the decryption and the PRF --
+    // G, the matrix expansion and H(ct), which leaves the end of the chain for it -- are one launch (keccak_split.h:
+    // k_dec_middle), and the last kernel is the one permutation of the KDF.  Same-box A/B, device pointers
+    // (profiles/r03_ab_latency_front_kernels.txt): n = 1 162 -> 135 us, 4096 183 -> 150, 16384 262 -> 232, 65536 a tie.
+    const bool middle = !N90 && !shared && (size_t)m <= FRONT_MAX_N;
+    RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
+    if (middle) {
+      if constexpr (!N90) {
+        k_zero32<<<1, 64, 0, st>>>(L.tailq);
+        LAUNCH_CHECK("k_zero32");
+        const unsigned nb_mat = blocks((size_t)m * P::NMAT, SPONGE_WG_SMALL), nb_h = blocks(2 * (size_t)m, SPLIT_WG);
+        RUN("k_dec_middle", st, k_dec_middle<P><<<nb_mat + 2 * nb_h, SPLIT_WG, 0, st>>>(m, (int)nb_mat, (int)nb_h, s, L.mat, L.tailq, L.tail_cap, c, ss + o * 32, L.small));
+        if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+      }
     } else {
-      RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
+      if constexpr (N90) {
+        RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
+      } else {
+        RUN_HASH("k_dec_mid", st, m, k_dec_mid<P>, k2_dec_mid<P>, m, s, sk_stride, L.small);
+      }
+      if (!shared)
+        if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     }
-    if constexpr (N90) {
-      RUN("k90_dec_mid", st, k90_dec_mid<P><<<blocks(m, 256), 256, 0, st>>>(m, s, sk_stride, L.small));
-    } else {
-      RUN_HASH("k_dec_mid", st, m, k_dec_mid<P>, k2_dec_mid<P>, m, s, sk_stride, L.small);
-    }
-    if (!shared && !front)
-      if (int rc = expand_matrix<P, N90>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
     if constexpr (N90) {
       AES_LAUNCH("k90_prf", st, k90_prf, (size_t)m * (2 * P::K + 1), (m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     } else {
@@ -512,7 +516,8 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
-      RUN_HASH("k_post", st, m, (k_post<P, true>), (k2_post<P, true>), m, c, L.small, s, sk_stride, ss + o * 32);
+      if (middle) RUN("k_kdf_dec", st, k2_kdf_dec<P><<<blocks(2 * (size_t)m, SPLIT_WG), SPLIT_WG, 0, st>>>(m, L.small, s, sk_stride, ss + o * 32));
+      else RUN_HASH("k_post", st, m, (k_post<P, true>), (k2_post<P, true>), m, c, L.small, s, sk_stride, ss + o * 32);
     }
   }
   return 0;

@@ -202,4 +202,15 @@ def test_front_kernels_agree_with_the_separate_launches(k):
     torch.cuda.synchronize()
     assert torch.equal(pk, pk_big[:n]) and torch.equal(sk, sk_big[:n])
     assert torch.equal(ct, ct_big[:n]) and torch.equal(ss, ss_big[:n])
+    # decapsulation: up to 65536 instances G, the matrix expansion and H(ct) are one launch and H(ct) waits in the
+    # output buffer (k_dec_middle, k2_kdf_dec); valid, corrupted and wrong-key ciphertexts through both routes
+    bad = ct_big.clone()
+    bad[::3, 5] ^= 0x21
+    sk_wrong = sk_big.clone()
+    sk_wrong[1::7] = sk_big[0]
+    for c_, s_ in ((ct_big, sk_big), (bad, sk_big), (ct_big, sk_wrong)):
+        big = kem.dec_dev(c_, s_)
+        small = kem.dec_dev(c_[:n].contiguous(), s_[:n].contiguous(), torch.full((n, 32), 0xA5, dtype=torch.uint8, device="cuda"))
+        torch.cuda.synchronize()
+        assert torch.equal(small, big[:n])
     assert torch.equal(kem.dec_dev(ct, sk), ss)

@@ -34,27 +34,10 @@ def test_no_kernel_source_mixes_the_phase_lock_with_a_data_barrier():
             users.append(name)
             assert not BARRIER.search(code), "%s calls the phase-locked permutation and uses a workgroup barrier" % name
     assert "kem_kernels.h" in users
-    # the files that do use data barriers (LDS tables, transposes) never permute; the translation unit of the
-    # poly-layout kernels reaches the sponge kernels through ONE header, dec_front.h (checked below)
-    arith = _code(os.path.join(CSRC, "arith_kernels.h")) + _code(os.path.join(CSRC, "wpoly.h")) + _code(os.path.join(CSRC, "fpoly.h")) + _code(os.path.join(CSRC, "poly.h"))
+    # the files that do use data barriers (LDS tables, transposes) never permute, and the translation
+    # unit of the poly-layout kernels does not even include keccak.h
+    arith = _code(os.path.join(CSRC, "kyber_arith.hip")) + _code(os.path.join(CSRC, "arith_kernels.h")) + _code(os.path.join(CSRC, "wpoly.h"))
     assert "keccak.h" not in arith and "kem_kernels" not in arith
-    tu = _code(os.path.join(CSRC, "kyber_arith.hip"))
-    assert not PERMUTES.search(tu) and "kem_kernels" not in tu and "keccak" not in tu.replace("dec_front.h", "")
-
-
-def test_dec_front_is_a_branch_on_the_workgroup_index_and_nothing_else():
-    """dec_front.h is the one kernel in which a poly-layout body (data barriers) and a sponge body (phase lock) meet.
-    It is sound because they never meet in a WORKGROUP: the kernel must be exactly `if (blockIdx.x < nb) body A; else
-    body B;` -- no statement before, between or after that could put both behaviours into one workgroup."""
-    code = _code(os.path.join(CSRC, "dec_front.h"))
-    kernels = code.split("__global__")[1:]
-    assert len(kernels) == 1
-    body = kernels[0][kernels[0].index("{") + 1:kernels[0].rindex("}", 0, kernels[0].rindex("}"))]
-    flat = " ".join(body.split())
-    m = re.fullmatch(r"if \(\(int\)blockIdx\.x < nb_arith\) dec_arith_body<P>\(blockIdx\.x, [^;]*\); "
-                     r"else sample_matrix_body<P, DEC_FRONT_WG, 0>\(blockIdx\.x - nb_arith, [^;]*\);", flat)
-    assert m, flat
-    assert not BARRIER.search(code) and not PERMUTES.search(code)  # it calls the two bodies and nothing of their insides
 
 
 def test_no_kernel_permutes_and_builds_a_shared_table():
