@@ -98,8 +98,9 @@ int kyber_batch_dec_mgpu_dev(int k, int nineties, int ndev, const int *devices, 
  * orders the launches and each call's stream first waits for an event recorded
  * behind the previous call's last kernel, so they may be issued concurrently
  * but do not run concurrently.  Encapsulations of up to 32768 instances of the
- * 90s sets (and unprepared shared-key calls) expand their matrices on a second,
- * library-owned stream beside the hashes: it
+ * 90s sets (and unprepared shared-key calls) expand their matrices, and
+ * decapsulations with one key for the whole batch hash their ciphertexts, on a
+ * second, library-owned stream beside the rest of the call: it
  * starts behind everything already queued on
  * `stream` and `stream` waits for it before the arithmetic, so the caller sees
  * one ordered stream either way.  Under stream capture the call stays on

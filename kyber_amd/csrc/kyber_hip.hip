@@ -472,8 +472,9 @@ int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_str
 // the kernel sequence of a decapsulation over a workspace that is already laid out
 template <class P, bool N90>
 int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st,
-            const int16_t* pmat = nullptr) {
+            const int16_t* pmat = nullptr, Side* sd = nullptr) {
   const bool shared = sk_stride == 0;
+  bool pending = false;
   if (shared && !pmat)
     if (int rc = expand_matrix<P, N90>(1, sk + 2 * P::PVB, 0, 1, L.smat, L, st)) return rc;
   const int16_t* mat = shared ? (pmat ? pmat : L.smat) : L.mat;
@@ -487,6 +488,18 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     // k_dec_middle), and the last kernel is the one permutation of the KDF.  Same-box A/B, device pointers
     // (profiles/r03_ab_latency_front_kernels.txt): n = 1 162 -> 135 us, 4096 183 -> 150, 16384 262 -> 232, 65536 a tie.
     const bool middle = !N90 && !shared && (size_t)m <= FRONT_MAX_N;
+    // One key for the whole batch (shared-key and prepared calls): no matrix to expand, so nothing long enough to hide
+    // H(ct) behind in one launch -- its nine permutations are longer than the rest of the chain together.  They run on
+    // the second stream from the start of the call and the caller's stream picks them up in front of the KDF.
+    const bool side_h = !N90 && shared && sd != nullptr && (size_t)m <= FRONT_MAX_N;
+    if (side_h) {
+      if constexpr (!N90) {
+        if (int rc = side_begin(sd, st)) return rc;
+        RUN("k_hash_ct", sd->s, k2_hash_ct<P><<<blocks(2 * (size_t)m, SPLIT_WG), SPLIT_WG, 0, sd->s>>>(m, c, ss + o * 32));
+        if (int rc = side_end(sd)) return rc;
+        pending = true;
+      }
+    }
     RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, sk_stride, L.small));
     if (middle) {
       if constexpr (!N90) {
@@ -516,7 +529,8 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
     if constexpr (N90) {
       RUN("k90_post", st, k90_post<P, true><<<blocks(m, 256), 256, 0, st>>>(m, c, L.small, s, sk_stride, ss + o * 32));
     } else {
-      if (middle) RUN("k_kdf_dec", st, k2_kdf_dec<P><<<blocks(2 * (size_t)m, SPLIT_WG), SPLIT_WG, 0, st>>>(m, L.small, s, sk_stride, ss + o * 32));
+      SIDE_JOIN(sd, pending, st);
+      if (middle || side_h) RUN("k_kdf_dec", st, k2_kdf_dec<P><<<blocks(2 * (size_t)m, SPLIT_WG), SPLIT_WG, 0, st>>>(m, L.small, s, sk_stride, ss + o * 32));
       else RUN_HASH("k_post", st, m, (k_post<P, true>), (k2_post<P, true>), m, c, L.small, s, sk_stride, ss + o * 32);
     }
   }
@@ -532,7 +546,7 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
   if (int rc = L.carve(chunk)) return rc;
-  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat);
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, sk_stride == 0 ? side_for(n, st) : nullptr);
 }
 
 // ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
