@@ -454,95 +454,17 @@ template <class P, int WG, int ABLATE>
 __device__ __forceinline__ void sample_matrix_body(unsigned bid, int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                    int transposed, int16_t* __restrict__ mat,
                                                    uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  __shared__ uint32_t stage[WG * MAT_STAGE_DW + 8];  // the last lane's remainder move may read 8 dwords past its row
-  const long job = (long)bid * WG + threadIdx.x;
-  const bool valid = job < njobs;
-  const long jc = valid ? job : (long)njobs - 1;
-  const int inst = (int)(jc / P::NMAT), e = (int)(jc % P::NMAT);
-  const int i = e / P::K, j = e % P::K;
-  const uint32_t x = transposed ? i : j, y = transposed ? j : i;  // ref/indcpa.c:173-176
-
-  u64p A[25], seed[4];
-  ld32B(rho + (size_t)inst * rho_stride, seed);
-  keccak_zero(A);
-#pragma unroll
-  for (int w = 0; w < 4; w++) A[w] = seed[w];
-  A[4].lo = x | y << 8 | 0x1F0000u;
-  A[20].hi = 0x80000000u;
-
-  uint32_t* row = stage + threadIdx.x * MAT_STAGE_DW;
-  const uint32_t row_addr = lds_addr(row);
-  uint32_t* out32 = reinterpret_cast<uint32_t*>(mat) + job * 128;
-  int ctr = valid ? 0 : 256;  // coefficients already in memory: a multiple of 32 until the entry is parked
-  int pend = 0;               // coefficients waiting at the front of the row, < 32
-  int blk = 0;
-
-  while (__any(ctr < 256)) {
-    keccak_f1600(A);
-    uint32_t H[42];
-#pragma unroll
-    for (int w = 0; w < 21; w++) { H[2 * w] = A[w].lo; H[2 * w + 1] = A[w].hi; }
-    auto part = [&](auto first) {
-      constexpr int G0 = decltype(first)::value;
-      const uint32_t w0 = row_addr + 2u * pend;
-      uint32_t waddr = w0;
-      if constexpr (ABLATE == 3 || ABLATE == 4) {
-        parse_range<G0, G0 + MAT_GROUPS, 42, true>(H, waddr, ABLATE == 3 ? row_addr : 0u);
-      } else if constexpr (ABLATE < 2) {
-        parse_range<G0, G0 + MAT_GROUPS, 42>(H, waddr);
-      } else {
-#pragma unroll
-        for (int w = 0; w < 42; w++) asm volatile("" ::"v"(H[w]));
-        waddr += 2 * (91 / MAT_PARTS);
-      }
-      const int cnt = pend + (int)((waddr - w0) >> 1);          // <= 31 + 28
-      const bool line = ctr < 256 && cnt >= 32;                 // one whole line leaves now
-      if constexpr (ABLATE == 0) {
-        if (line) {
-          uint4* dst = reinterpret_cast<uint4*>(out32 + (ctr >> 1));
-#pragma unroll
-          for (int q = 0; q < 4; q++) dst[q] = make_uint4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
-        }
-      }
-      if (line) ctr += 32;
-      const int left = line ? cnt - 32 : cnt;
-      pend = ctr < 256 ? left : 0;
-      if (line && pend > 0) {  // the remainder (<= 27 coefficients) moves to the front
-#pragma unroll
-        for (int d = 0; d < 14; d += 2) {
-          const uint32_t a = row[16 + d], b = row[17 + d];
-          row[d] = a;
-          row[d + 1] = b;
-        }
-      }
-    };
-    part(std::integral_constant<int, 0>{});
-    part(std::integral_constant<int, MAT_GROUPS>{});
-    part(std::integral_constant<int, 2 * MAT_GROUPS>{});
-    part(std::integral_constant<int, 3 * MAT_GROUPS>{});
-    if (++blk == MAT_MAIN_BLOCKS && tailq != nullptr && ctr < 256) {
-      const uint32_t slot = atomicAdd(tailq, 1u);
-      if (slot < tail_cap) {
-        // parked entries hand over ctr + pend coefficients in memory: flush the pending ones (a
-        // partial line; an odd last coefficient travels in the low half of its dword)
-        for (int d = 0; 2 * d < pend; d++) out32[(ctr >> 1) + d] = row[d];
-        uint32_t* r = tailq + TAILQ_HDR_DW + (size_t)slot * TAILQ_REC_DW;
-#pragma unroll
-        for (int w = 0; w < 24; w += 2)
-          *reinterpret_cast<uint4*>(r + 2 * w) = make_uint4(A[w].lo, A[w].hi, A[w + 1].lo, A[w + 1].hi);
-        *reinterpret_cast<uint4*>(r + 48) = make_uint4(A[24].lo, A[24].hi, (uint32_t)job, (uint32_t)(ctr + pend));
-        ctr = 256;
-        pend = 0;
-      }
-    }
-  }
+#define KY_BID bid
+#include "kem_sample_body.inc"
+#undef KY_BID
 }
-
 template <class P, int WG = SPONGE_WG, int ABLATE = 0>
 __global__ void __launch_bounds__(WG, 4) k_sample_matrix(int njobs, const uint8_t* __restrict__ rho, size_t rho_stride,
                                                                    int transposed, int16_t* __restrict__ mat,
                                                                    uint32_t* __restrict__ tailq, uint32_t tail_cap) {
-  sample_matrix_body<P, WG, ABLATE>(blockIdx.x, njobs, rho, rho_stride, transposed, mat, tailq, tail_cap);
+#define KY_BID blockIdx.x
+#include "kem_sample_body.inc"
+#undef KY_BID
 }
 
 // Finishes the entries parked by k_sample_matrix: one work-item per queue

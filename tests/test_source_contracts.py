@@ -24,7 +24,7 @@ def _code(path):
 
 def test_no_kernel_source_mixes_the_phase_lock_with_a_data_barrier():
     users = []
-    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip"))):
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.inc"))):
         code = _code(path)
         name = os.path.basename(path)
         if name == "keccak.h":
