@@ -5,7 +5,9 @@ Test infrastructure (uses oracle_lib.py beside it), run by hand, not collected b
 
     python3 tests/soak.py [seconds per set = 60] [batch = 2^19]
     python3 tests/soak.py 40 -40000      # a negative batch: every round draws its size from [1, 40000] (the small-batch routes)
+    python3 tests/soak.py 90 524288 7    # a third argument moves every set's seed: other inputs than the last run's
 """
+import hashlib
 import os
 import sys
 import threading
@@ -21,13 +23,17 @@ import oracle_lib  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 nmax = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 19
+shift = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 threads = 16
+with open(kyber_amd.lib.library_path(), "rb") as f:
+    print("library sha256 %s, seed shift %d" % (hashlib.sha256(f.read()).hexdigest()[:12], shift), flush=True)
 for k in (3, 2, 4):
     for n90 in (0, 1):
         impl = "avx2" if oracle_lib.has_avx2() else "ref"
         ref = oracle_lib.RefLib(impl, k, n90)
         kem = kyber_amd.KyberHip(k, n90)
-        rng = np.random.default_rng(1_000_003 * k + n90)
+        seed = 1_000_003 * k + n90 + 7919 * shift
+        rng = np.random.default_rng(seed)
         t0, total, rounds = time.time(), 0, 0
         while time.time() - t0 < budget:
             n = nmax if nmax > 0 else int(rng.integers(1, -nmax + 1))
@@ -56,8 +62,7 @@ for k in (3, 2, 4):
             for name, a, r in (("pk", pk, rpk), ("sk", sk, rsk), ("ct", ct, rct), ("ss", ss, rss), ("dec", got, rdec)):
                 if not np.array_equal(a, r):
                     i = int(np.nonzero((a != r).any(axis=1))[0][0])
-                    print("MISMATCH Kyber%d%s %s instance %d of round %d (seed %d)" % (256 * k, "-90s" if n90 else "", name, i, rounds,
-                                                                                        1_000_003 * k + n90), flush=True)
+                    print("MISMATCH Kyber%d%s %s instance %d of round %d (seed %d)" % (256 * k, "-90s" if n90 else "", name, i, rounds, seed), flush=True)
                     sys.exit(1)
             total += n
             rounds += 1
