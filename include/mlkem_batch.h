@@ -26,7 +26,11 @@
  * random inputs of the *_internal algorithms: d || z (64 bytes) for keygen,
  * m (32 bytes) for encaps; NULL draws them from randombytes().  Return 0 or a
  * negative KYBER_HIP_* code.  The *_dev forms take device pointers and a
- * hipStream_t like those of kyber_batch.h.
+ * hipStream_t like those of kyber_batch.h, under the same rules (16-byte
+ * aligned pointers, else KYBER_HIP_EINVAL; calls may be captured in a graph).
+ * Batches up to 65 536 take the small-batch routes of kyber_batch.h, on one
+ * stream: during a decapsulation ss holds the rejection key J(z || c) until
+ * the last kernel of the call has selected the secret.
  */
 #ifndef MLKEM_BATCH_H
 #define MLKEM_BATCH_H

@@ -350,4 +350,119 @@ __global__ void __launch_bounds__(SPLIT_WG) k2_kdf_dec(int n, const uint8_t* __r
   ks_st32B(ss + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
 }
 
+// ------------------------------------------------------------------ ML-KEM (FIPS 203) on the same routes
+// The FO glue of kem_kernels.h's ML-KEM kernels (k_ml_kp_pre, k_ml_enc_pre, k_ml_post_dec) on pairs, and the two
+// one-launch stages of a small batch: what the standard changed moves MORE work off the end of the chain than
+// round 3 allowed -- an encapsulation ends with the ciphertext (the shared secret is G's first half, nothing is
+// hashed behind the encryption), and a decapsulation's rejection key J(z || c) needs only inputs the caller handed
+// in, so it runs beside the matrix expansion and G, and what is left behind the re-encryption is a select.
+
+// keypair, before: (rho, sigma) = G(d || k)
+__global__ void __launch_bounds__(SPLIT_WG) k2_ml_kp_pre(int n, int k, const uint8_t* __restrict__ coins, uint8_t* __restrict__ small) {
+  const int g = blockIdx.x * SPLIT_WG + threadIdx.x, i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
+  uint32_t d[4], A[25];
+  ks_ld32B(coins + (size_t)i * 64, h, d);
+  ks_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = d[w];
+  A[4] = h.low((uint32_t)k | 0x0600u);  // byte 32 = k, then the SHA3 domain byte
+  A[8] = h.high(0x80000000u);
+  ks_f1600(A, h);
+  uint8_t* s = small + (size_t)i * SMALL;
+  ks_st32B(s, h, A[0], A[1], A[2], A[3]);
+  ks_st32B(s + 32, h, A[4], A[5], A[6], A[7]);
+}
+
+// encaps: (K, r) = G(m || H(ek)); the shared secret is K itself
+template <class P>
+__device__ __forceinline__ void ks_ml_enc_pre_body(int g, int n, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                   uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
+  const int i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
+  uint32_t A[25], m[4], hp[4];
+  ks_ld32B(coins + (size_t)i * 32, h, m);
+  ks_absorb_words<136, 0x06, P::PKB>(A, pk + (size_t)i * P::PKB, h);
+#pragma unroll
+  for (int w = 0; w < 4; w++) hp[w] = A[w];
+  ks_sha3_512_64(A, m, hp, h);
+  uint8_t* s = small + (size_t)i * SMALL;
+  ks_st32B(s, h, m[0], m[1], m[2], m[3]);
+  ks_st32B(ss + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
+  ks_st32B(s + 64, h, A[4], A[5], A[6], A[7]);
+}
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG, 4) k_ml_enc_front(int n, int nb_pre, const uint8_t* __restrict__ coins, const uint8_t* __restrict__ pk,
+                                                              size_t pk_stride_rho, uint8_t* __restrict__ small, uint8_t* __restrict__ ss,
+                                                              int16_t* __restrict__ mat, uint32_t* __restrict__ tailq, uint32_t tail_cap) {
+  if ((int)blockIdx.x < nb_pre)
+    ks_ml_enc_pre_body<P>(blockIdx.x * SPLIT_WG + threadIdx.x, n, coins, pk, small, ss);
+  else
+    sample_matrix_body<P, SPONGE_WG_SMALL, 0>(blockIdx.x - nb_pre, n * P::NMAT, pk + P::PVB, pk_stride_rho, 1, mat, tailq, tail_cap);
+}
+
+// decaps: the rejection key J(z || c) = SHAKE256(z || c, 32) into `out`.  Word w of the message is z's word w for
+// w < 4 and the ciphertext's word w - 4 after it; every block is loaded while the one before it is permuted.
+template <class P>
+__device__ __forceinline__ void ks_ml_j_body(int g, int n, const uint8_t* __restrict__ ct, const uint8_t* __restrict__ sk, size_t sk_stride,
+                                             uint8_t* __restrict__ out) {
+  const int i = g >> 1;
+  if (i >= n) return;
+  const KsHalf h = ks_half(g & 1);
+  constexpr int RW = 17, TOTW = 4 + P::CTB / 8, NFULL = TOTW / RW, TAILW = TOTW % RW;
+  static_assert(NFULL >= 2, "the first block is peeled");
+  const uint8_t* c = ct + (size_t)i * P::CTB;  // word w of the message, w >= 4, lies at c + 8 (w - 4)
+  uint32_t A[25], nx[RW];
+  ks_zero(A);
+#pragma unroll
+  for (int w = 0; w < 4; w++) A[w] = ks_ld(sk + (size_t)i * sk_stride + 2 * P::PVB + 64 + 8 * w, h);
+#pragma unroll
+  for (int w = 4; w < RW; w++) A[w] = ks_ld(c + 8 * (w - 4), h);
+#pragma unroll
+  for (int w = 0; w < RW; w++) nx[w] = ks_ld(c + 8 * (RW + w - 4), h);
+  ks_f1600(A, h);
+#pragma unroll 1
+  for (int b = 1; b < NFULL; b++) {
+#pragma unroll
+    for (int w = 0; w < RW; w++) A[w] ^= nx[w];
+#pragma unroll
+    for (int w = 0; w < RW; w++) {  // the block after this one; past the end the last word again (not absorbed)
+      const int idx = (b + 1) * RW + w;
+      nx[w] = ks_ld(c + 8 * ((idx < TOTW ? idx : TOTW - 1) - 4), h);
+    }
+    ks_f1600(A, h);
+  }
+#pragma unroll
+  for (int w = 0; w < TAILW; w++) A[w] ^= nx[w];
+  A[TAILW] ^= h.low(0x1Fu);
+  A[RW - 1] ^= h.high(0x80000000u);
+  ks_f1600(A, h);
+  ks_st32B(out + (size_t)i * 32, h, A[0], A[1], A[2], A[3]);
+}
+// the middle launch of a small decapsulation: matrix expansion | J(z || c) on pairs | G(m' || h) on pairs
+template <class P>
+__global__ void __launch_bounds__(SPLIT_WG, 4) k_ml_dec_middle(int n, int nb_mat, int nb_h, const uint8_t* __restrict__ sk, int16_t* __restrict__ mat,
+                                                               uint32_t* __restrict__ tailq, uint32_t tail_cap, const uint8_t* __restrict__ ct,
+                                                               uint8_t* __restrict__ ss, uint8_t* __restrict__ small) {
+  const int b = (int)blockIdx.x;
+  if (b < nb_mat)
+    sample_matrix_body<P, SPONGE_WG_SMALL, 0>(blockIdx.x, n * P::NMAT, sk + 2 * P::PVB, P::SKB, 1, mat, tailq, tail_cap);
+  else if (b < nb_mat + nb_h)
+    ks_ml_j_body<P>((b - nb_mat) * SPLIT_WG + threadIdx.x, n, ct, sk, P::SKB, ss);
+  else
+    ks_dec_mid_body<P>((b - nb_mat - nb_h) * SPLIT_WG + threadIdx.x, n, sk, P::SKB, small);
+}
+// ss holds J(z || c) on entry; ss = (c == c') ? K' : J, selected without a branch.  One work-item per dword.
+__global__ void __launch_bounds__(256) k_ml_select(int n, const uint8_t* __restrict__ small, uint8_t* __restrict__ ss) {
+  const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 3, w = t & 7;
+  if (i >= n) return;
+  const uint8_t* s = small + (size_t)i * SMALL;
+  const uint32_t mask = 0u - (*reinterpret_cast<const uint32_t*>(s + 96) != 0u ? 1u : 0u);
+  const uint32_t kb = *reinterpret_cast<const uint32_t*>(s + 32 + 4 * w);
+  uint32_t* o = reinterpret_cast<uint32_t*>(ss + (size_t)i * 32) + w;
+  *o = kb ^ (mask & (kb ^ *o));
+}
+
 }  // namespace ky

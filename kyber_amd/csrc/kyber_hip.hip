@@ -563,11 +563,15 @@ int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hip
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
     uint8_t *p = ek + o * P::PKB, *s = dk + o * P::SKB;
-    RUN("k_ml_kp_pre", st, k_ml_kp_pre<<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, P::K, c, L.small));
-    if (int rc = expand_matrix<P, false>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
-    RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    RUN_HASH("k_ml_kp_pre", st, m, k_ml_kp_pre, k2_ml_kp_pre, m, P::K, c, L.small);
+    if ((size_t)m <= FRONT_MAX_N) {  // small batches: matrix expansion and PRF as one launch, as in keypair_dev
+      if (int rc = kp_front<P>(m, L, st)) return rc;
+    } else {
+      if (int rc = expand_matrix<P, false>(m, L.small, SMALL, 0, L.mat, L, st)) return rc;
+      RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * 2 * P::K, sponge_wg((size_t)m * 2 * P::K)), sponge_wg((size_t)m * 2 * P::K), 0, st>>>(m, 2 * P::K, 2 * P::K, L.small, 32, L.prf));
+    }
     RUN("k_kp_arith", st, launch_kp_arith<P>(st, m, L.small, L.mat, L.prf, p, s));
-    RUN("k_kp_post", st, k_kp_post<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, p, s));  // dk tail = H(ek) || z, as in round 3
+    RUN_HASH("k_kp_post", st, m, k_kp_post<P>, k2_kp_post<P>, m, c, p, s);  // dk tail = H(ek) || z, as in round 3
   }
   return 0;
 }
@@ -585,8 +589,16 @@ int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = ek + o * P::PKB;
     uint8_t* c = ct + o * P::CTB;
-    RUN("k_ml_enc_pre", st, k_ml_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, L.small, ss + o * 32));
-    if (int rc = expand_matrix<P, false>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
+    if ((size_t)m <= FRONT_MAX_N) {  // small batches: H(ek), G and the matrix expansion as one launch (keccak_split.h)
+      k_zero32<<<1, 64, 0, st>>>(L.tailq);
+      LAUNCH_CHECK("k_zero32");
+      const unsigned nb_pre = blocks(2 * (size_t)m, SPLIT_WG), nb_mat = blocks((size_t)m * P::NMAT, SPONGE_WG_SMALL);
+      RUN("k_ml_enc_front", st, k_ml_enc_front<P><<<nb_pre + nb_mat, SPLIT_WG, 0, st>>>(m, (int)nb_pre, coins + o * 32, p, P::PKB, L.small, ss + o * 32, L.mat, L.tailq, L.tail_cap));
+      if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+    } else {
+      RUN("k_ml_enc_pre", st, k_ml_enc_pre<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, coins + o * 32, p, L.small, ss + o * 32));
+      if (int rc = expand_matrix<P, false>(m, p + P::PVB, P::PKB, 1, L.mat, L, st)) return rc;
+    }
     RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     RUN("k_enc_arith", st, launch_enc_arith<P, false>(st, m, p, P::PKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, c));
   }
@@ -606,13 +618,25 @@ int ml_dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, hipS
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
     const uint8_t* s = dk + o * P::SKB;
+    // small batches: G, the matrix expansion and the rejection key J(z || c) -- which waits in the caller's ss
+    // buffer -- as one launch behind the decryption; behind the re-encryption only a select is left (keccak_split.h)
+    const bool middle = (size_t)m <= FRONT_MAX_N;
     RUN("k_dec_arith", st, launch_dec_arith<P>(st, m, c, s, P::SKB, L.small));
-    RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, P::SKB, L.small));
-    if (int rc = expand_matrix<P, false>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
+    if (middle) {
+      k_zero32<<<1, 64, 0, st>>>(L.tailq);
+      LAUNCH_CHECK("k_zero32");
+      const unsigned nb_mat = blocks((size_t)m * P::NMAT, SPONGE_WG_SMALL), nb_h = blocks(2 * (size_t)m, SPLIT_WG);
+      RUN("k_ml_dec_middle", st, k_ml_dec_middle<P><<<nb_mat + 2 * nb_h, SPLIT_WG, 0, st>>>(m, (int)nb_mat, (int)nb_h, s, L.mat, L.tailq, L.tail_cap, c, ss + o * 32, L.small));
+      if (L.tail_cap) RUN("k_sample_matrix_tail", st, k_sample_matrix_tail<<<blocks(L.tail_cap, 64), 64, 0, st>>>(L.tailq, L.tail_cap, L.mat));
+    } else {
+      RUN("k_dec_mid", st, k_dec_mid<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, s, P::SKB, L.small));
+      if (int rc = expand_matrix<P, false>(m, s + 2 * P::PVB, P::SKB, 1, L.mat, L, st)) return rc;
+    }
     RUN("k_prf", st, k_prf<P><<<blocks((size_t)m * (2 * P::K + 1), sponge_wg((size_t)m * (2 * P::K + 1))), sponge_wg((size_t)m * (2 * P::K + 1)), 0, st>>>(m, 2 * P::K + 1, P::K, L.small, 64, L.prf));
     RUN("k_enc_arith_cmp", st,
         launch_enc_arith<P, true>(st, m, s + P::PVB, P::SKB, L.small, L.mat, (size_t)P::NMAT * 256, L.prf, const_cast<uint8_t*>(c)));
-    RUN("k_ml_post_dec", st, k_ml_post_dec<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, s, P::SKB, ss + o * 32));
+    if (middle) RUN("k_ml_select", st, k_ml_select<<<blocks(8 * (size_t)m, 256), 256, 0, st>>>(m, L.small, ss + o * 32));
+    else RUN("k_ml_post_dec", st, k_ml_post_dec<P><<<blocks(m, sponge_wg(m)), sponge_wg(m), 0, st>>>(m, c, L.small, s, P::SKB, ss + o * 32));
   }
   return 0;
 }
@@ -1550,16 +1574,19 @@ int mlkem_batch_decaps(int k, size_t n, uint8_t* ss, const uint8_t* ct, const ui
 }
 int mlkem_batch_keypair_dev(int k, size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, void* stream) {
   if (!ek || !dk || !coins || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ek, dk, coins})) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;
   DISPATCH_ML(k, ml_keypair_dev, n, ek, dk, coins, static_cast<hipStream_t>(stream));
 }
 int mlkem_batch_encaps_dev(int k, size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins, void* stream) {
   if (!ct || !ss || !ek || !coins || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ct, ss, ek, coins})) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;
   DISPATCH_ML(k, ml_enc_dev, n, ct, ss, ek, coins, static_cast<hipStream_t>(stream));
 }
 int mlkem_batch_decaps_dev(int k, size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, void* stream) {
   if (!ss || !ct || !dk || k < 2 || k > 4) return KYBER_HIP_EINVAL;
+  if (!dev_aligned({ss, ct, dk})) return KYBER_HIP_EINVAL;
   if (n == 0) return 0;
   DISPATCH_ML(k, ml_dec_dev, n, ss, ct, dk, static_cast<hipStream_t>(stream));
 }
