@@ -303,6 +303,15 @@ void kyber_hip_host_free(void *p);
 /* instances processed per internal pass (workspace sizing); 0 restores the default
  * (2^19), more than 2^24 is refused with KYBER_HIP_EINVAL */
 int kyber_hip_set_chunk(size_t instances);
+/* Workspaces per device, 1 (the default) to 8.  No counterpart in the reference, whose calls
+ * share nothing.  With one workspace the GPU work of any two pipeline calls on a device is
+ * ordered, whatever streams they are queued on.  With s > 1, device-pointer calls of up to
+ * 65 536 instances that arrive on different streams (e.g. from the request threads of a
+ * server) take different workspaces and run side by side on the device, which such batches
+ * leave mostly idle; calls on one stream, larger batches and calls under stream capture
+ * behave as before.  Each extra workspace is sized by the largest batch it has served
+ * (about 5.7 KB per Kyber768 instance).  Takes effect for the calls that start after it. */
+int kyber_hip_set_workspace_slots(int slots);
 /* Tuning/test aid (no counterpart in the reference): upper bound on the records
  * of the matrix sampler's tail queue per pass.  Entries that do not fit are
  * finished by the main kernel itself, so any value gives the same output;

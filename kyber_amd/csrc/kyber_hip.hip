@@ -51,8 +51,20 @@ struct Workspace {
   hipEvent_t idle = nullptr;        // recorded after the last kernel that uses the workspace
   hipStream_t last = nullptr;       // ... on this stream
   bool used = false;
+  uint64_t stamp = 0;               // order of last use among the device's workspaces
 };
-Workspace g_ws[MAX_DEV];
+// Workspaces per device.  One by default: the GPU work of any two pipeline calls on a device is then ordered
+// (WsUse).  kyber_hip_set_workspace_slots(s > 1) lets batches up to POOL_MAX_N instances that arrive on DIFFERENT
+// streams take different workspaces, so their kernels overlap on the device -- small batches leave most of it
+// idle ("small batches") and a server with several request threads wants them side by side.
+// Every workspace on its own keeps the one-workspace protocol, so the choice of slot is a matter of speed only.
+// Larger batches fill the chip alone and calls under stream capture must find the memory a call outside
+// capture laid out: both always take slot 0.
+constexpr int MAX_SLOTS = 8;
+constexpr size_t POOL_MAX_N = 65536;
+Workspace g_ws[MAX_DEV][MAX_SLOTS];
+uint64_t g_ws_stamp[MAX_DEV];
+std::atomic<int> g_slots{1};
 std::atomic<size_t> g_chunk{DEFAULT_CHUNK};
 std::atomic<size_t> g_tail_cap_max{(size_t)-1};
 // One lock per device (workspace + launch order), so that host threads driving
@@ -66,11 +78,11 @@ inline std::mutex& dev_mutex(std::mutex (&arr)[MAX_DEV]) {
   return arr[dev];
 }
 
-int ws_reserve(size_t bytes, uint8_t** out) {
+int ws_reserve(int slot, size_t bytes, uint8_t** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
-  Workspace& w = g_ws[dev];
+  if (dev < 0 || dev >= MAX_DEV || slot < 0 || slot >= MAX_SLOTS) return KYBER_HIP_EINVAL;
+  Workspace& w = g_ws[dev][slot];
   if (w.bytes < bytes) {
     if (w.base) {
       HIP_TRY(hipDeviceSynchronize());
@@ -85,20 +97,52 @@ int ws_reserve(size_t bytes, uint8_t** out) {
   return 0;
 }
 
-// The workspace is one per device, so the GPU work of two pipeline calls must not
-// overlap even when they are queued on different streams (or from different
+// The slot for a batch of up to POOL_MAX_N instances outside capture, by speed: the one this stream used last
+// (ordered behind it anyway), else one never used, else one whose last call has finished, else the one used
+// longest ago (the call then waits for it).
+int pick_slot(int dev, int nslot, hipStream_t st) {
+  Workspace* ws = g_ws[dev];
+  int best = -1;
+  for (int s = 0; s < nslot; s++)
+    if (ws[s].used && ws[s].last == st && (best < 0 || ws[s].stamp > ws[best].stamp)) best = s;
+  if (best >= 0) return best;
+  for (int s = 0; s < nslot; s++)
+    if (!ws[s].used) return s;
+  for (int s = 0; s < nslot; s++) {
+    if (hipEventQuery(ws[s].idle) == hipSuccess) return s;
+    (void)hipGetLastError();  // "not ready" is an answer, not a failure of the launch that follows
+  }
+  best = 0;
+  for (int s = 1; s < nslot; s++)
+    if (ws[s].stamp < ws[best].stamp) best = s;
+  return best;
+}
+bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // unknown: the conservative answer
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
+
+// The GPU work of two pipeline calls that share a workspace must not overlap even when
+// they are queued on different streams (or from different
 // host threads): a call first makes its stream wait for the event the previous
 // call recorded behind its last kernel.  Calls on one stream cost nothing extra.
 struct WsUse {
   hipStream_t st;
   Workspace* w = nullptr;
+  int slot = 0;
+  int dev = 0;
   int rc = 0;  // checked by the caller before it launches anything
-  explicit WsUse(hipStream_t s) : st(s) {
-    int dev = 0;
+  WsUse(hipStream_t s, size_t n) : st(s) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) { rc = hip_fail(e, "hipGetDevice"); return; }
     if (dev < 0 || dev >= MAX_DEV) { rc = KYBER_HIP_EINVAL; return; }
-    Workspace* ws = &g_ws[dev];
+    const int nslot = g_slots.load();
+    if (nslot > 1 && n <= POOL_MAX_N && !stream_capturing(st)) slot = pick_slot(dev, nslot, st);
+    Workspace* ws = &g_ws[dev][slot];
     if (!ws->idle && (e = hipEventCreateWithFlags(&ws->idle, hipEventDisableTiming)) != hipSuccess) {
       ws->idle = nullptr;
       rc = hip_fail(e, "hipEventCreateWithFlags");
@@ -121,6 +165,7 @@ struct WsUse {
     }
     w->last = st;
     w->used = true;
+    w->stamp = ++g_ws_stamp[dev];
   }
 };
 
@@ -150,9 +195,9 @@ struct Layout {
     const size_t cap_max = g_tail_cap_max.load();
     tail_cap = (uint32_t)(cap < cap_max ? cap : cap_max);
   }
-  int carve(size_t chunk) {
+  int carve(size_t chunk, const WsUse& use) {
     uint8_t* b;
-    int rc = ws_reserve(need(chunk), &b);
+    int rc = ws_reserve(use.slot, need(chunk), &b);
     if (rc) return rc;
     place(b, chunk);
     return 0;
@@ -311,9 +356,9 @@ struct Side {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
 };
-Side g_side[MAX_DEV];  // under g_dev_mu like the workspace
+Side g_side[MAX_DEV][MAX_SLOTS];  // one per workspace, under g_dev_mu like it
 
-Side* side_for(size_t n, hipStream_t st) {
+Side* side_for(size_t n, hipStream_t st, int slot) {
   if (n > SIDE_MAX_N) return nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -322,7 +367,7 @@ Side* side_for(size_t n, hipStream_t st) {
   }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  Side& sd = g_side[dev];
+  Side& sd = g_side[dev][slot];
   if (!sd.s) {
     Side t;
     // Highest priority: the runtime keeps the hardware queues of a priority level apart from those of the
@@ -379,12 +424,12 @@ int expand_matrix_beside(Side* sd, bool* pending, int insts, const uint8_t* rho,
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
+  if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
@@ -420,15 +465,15 @@ template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st,
             const int16_t* pmat = nullptr, const uint8_t* phpk = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   const bool shared = pk_stride == 0;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
+  if (int rc = L.carve(chunk, use)) return rc;
   const bool front = !N90 && !shared && n <= FRONT_MAX_N;  // one launch for the hashes in front and the matrix expansion
-  Side* sd = front ? nullptr : side_for(n, st);
+  Side* sd = front ? nullptr : side_for(n, st, use.slot);
   bool pending = false;
   if (shared && !pmat) {
     if (int rc = expand_matrix_beside<P, N90>(sd, &pending, 1, pk + P::PVB, 0, 1, L.smat, L, st)) return rc;
@@ -540,25 +585,25 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
 template <class P, bool N90>
 int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st, const int16_t* pmat = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
-  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, sk_stride == 0 ? side_for(n, st) : nullptr);
+  if (int rc = L.carve(chunk, use)) return rc;
+  return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, sk_stride == 0 ? side_for(n, st, use.slot) : nullptr);
 }
 
 // ---- ML-KEM (FIPS 203) pipelines: the Kyber kernel sequences with the standard's FO glue ----
 template <class P>
 int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
+  if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = coins + o * 64;
@@ -579,12 +624,12 @@ int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hip
 template <class P>
 int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
+  if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* p = ek + o * P::PKB;
@@ -608,12 +653,12 @@ int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint
 template <class P>
 int ml_dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st);
+  WsUse use(st, n);
   if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
   Layout<P> L;
-  if (int rc = L.carve(chunk)) return rc;
+  if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
     const int m = (int)(n - o < chunk ? n - o : chunk);
     const uint8_t* c = ct + o * P::CTB;
@@ -1879,6 +1924,12 @@ int kyber_hip_set_chunk(size_t instances) {
   return 0;
 }
 
+int kyber_hip_set_workspace_slots(int slots) {
+  if (slots < 1 || slots > MAX_SLOTS) return KYBER_HIP_EINVAL;
+  g_slots = slots;
+  return 0;
+}
+
 int kyber_hip_set_tail_capacity(size_t records) {
   g_tail_cap_max = records;
   return 0;
@@ -1889,21 +1940,26 @@ int kyber_hip_set_tail_capacity(size_t records) {
 static int release_device(int dev) {
   std::lock_guard<std::mutex> hlk(g_host_mu[dev]);  // same order as the host-pointer calls: host lock, then workspace lock
   std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
-  const bool any = g_ws[dev].base || g_host[dev] || g_scratch_ptr[dev] || g_side[dev].s;
+  bool any = g_host[dev] || g_scratch_ptr[dev];
+  for (int s = 0; s < MAX_SLOTS; s++) any = any || g_ws[dev][s].base || g_ws[dev][s].idle || g_side[dev][s].s;
   if (!any) return 0;
   HIP_TRY(hipSetDevice(dev));
   HIP_TRY(hipDeviceSynchronize());
-  if (g_side[dev].s) {
-    (void)hipStreamDestroy(g_side[dev].s);
-    (void)hipEventDestroy(g_side[dev].fork);
-    (void)hipEventDestroy(g_side[dev].join);
-    g_side[dev] = Side{};
-  }
-  if (g_ws[dev].base) {
-    HIP_TRY(hipMemset(g_ws[dev].base, 0, g_ws[dev].bytes));  // sigma, r, m, Kbar, PRF bytes of the last call
-    HIP_TRY(hipFree(g_ws[dev].base));
-    if (g_ws[dev].idle) (void)hipEventDestroy(g_ws[dev].idle);
-    g_ws[dev] = Workspace{};
+  for (int s = 0; s < MAX_SLOTS; s++) {
+    Side& sd = g_side[dev][s];
+    if (sd.s) {
+      (void)hipStreamDestroy(sd.s);
+      (void)hipEventDestroy(sd.fork);
+      (void)hipEventDestroy(sd.join);
+      sd = Side{};
+    }
+    Workspace& w = g_ws[dev][s];
+    if (w.base) {
+      HIP_TRY(hipMemset(w.base, 0, w.bytes));  // sigma, r, m, Kbar, PRF bytes of the last call
+      HIP_TRY(hipFree(w.base));
+    }
+    if (w.idle) (void)hipEventDestroy(w.idle);
+    w = Workspace{};
   }
   if (HostCtx* c = g_host[dev]) {
     if (c->staging) {

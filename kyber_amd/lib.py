@@ -121,6 +121,7 @@ def library():
         "kyber_batch_poly_mul_fused_canon_dev": [sz, i16p, i16p, i16p, vp],
         "kyber_hip_set_chunk": [sz],
         "kyber_hip_set_tail_capacity": [sz],
+        "kyber_hip_set_workspace_slots": [ci],
         "kyber_hip_profile_enable": [ci],
         "kyber_hip_profile_read": [ctypes.c_char_p, sz],
         "kyber_hip_release": [],
@@ -553,6 +554,12 @@ def noalloc_max_n():
 
 def set_chunk(instances):
     _check(library().kyber_hip_set_chunk(int(instances)), "kyber_hip_set_chunk")
+
+
+def set_workspace_slots(slots):
+    """Workspaces per device (1..8): with more than one, batches of up to 65 536 instances on different
+    streams run side by side on the device (include/kyber_batch.h: kyber_hip_set_workspace_slots)."""
+    _check(library().kyber_hip_set_workspace_slots(int(slots)), "kyber_hip_set_workspace_slots")
 
 
 class _Pinned:

@@ -1,0 +1,88 @@
+"""GPU: kyber_hip_set_workspace_slots (include/kyber_batch.h).  With several workspaces per device, small batches
+that arrive on different streams from different host threads overlap on the device; every byte must be what the
+one-workspace library gives (itself pinned by the oracle, the vectors and the soak), for the SHAKE sets, a 90s
+set (its second stream is per workspace), ML-KEM, and with a large batch (always slot 0) in the mix."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import kyber_amd
+from kyber_amd import lib as kl
+
+pytestmark = pytest.mark.gpu
+
+
+def _job(kind, k, n90, n, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    kc = torch.randint(0, 256, (n, 64), dtype=torch.uint8, device="cuda", generator=g)
+    ec = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    if kind == "ml":
+        ml = kyber_amd.MlKemHip(k)
+
+        def run():
+            ek, dk = ml.keypair_dev(kc)
+            ct, ss = ml.encaps_dev(ek, ec)
+            bad = ct.clone()
+            bad[::3, 5] ^= 1
+            return ek, dk, ct, ss, ml.decaps_dev(bad, dk)
+    else:
+        kem = kyber_amd.KyberHip(k, n90)
+
+        def run():
+            pk, sk = kem.keypair_dev(kc)
+            ct, ss = kem.enc_dev(pk, ec)
+            bad = ct.clone()
+            bad[::3, 5] ^= 1
+            return pk, sk, ct, ss, kem.dec_dev(bad, sk)
+    return run
+
+
+def test_slots_argument_range():
+    L = kl.library()
+    assert L.kyber_hip_set_workspace_slots(0) == -1 and L.kyber_hip_set_workspace_slots(9) == -1
+    assert L.kyber_hip_set_workspace_slots(8) == 0 and L.kyber_hip_set_workspace_slots(1) == 0
+
+
+def test_concurrent_streams_on_several_workspaces_give_the_same_bytes(oracle):
+    jobs = [("ky", 3, 0, 1, 11), ("ky", 3, 0, 300, 12), ("ky", 2, 0, 5000, 13), ("ky", 4, 0, 20000, 14),
+            ("ky", 3, 1, 700, 15), ("ml", 3, 0, 900, 16), ("ky", 3, 0, 70000, 17), ("ky", 3, 0, 40, 18)]
+    runs = [_job(*j) for j in jobs]
+    want = [tuple(t.clone() for t in r()) for r in runs]   # one workspace, one stream
+    torch.cuda.synchronize()
+    # the one-workspace results of the first job against the oracle, so that the comparison below is anchored here too
+    kc = torch.randint(0, 256, (1, 64), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+    opk, osk = oracle.keypair(3, kc.cpu().numpy())
+    assert np.array_equal(want[0][0].cpu().numpy(), opk) and np.array_equal(want[0][1].cpu().numpy(), osk)
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            for _ in range(6 if jobs[i][3] >= 20000 else 25):
+                with torch.cuda.stream(st):
+                    got = runs[i]()
+                st.synchronize()
+                for a, b in zip(got, want[i]):
+                    if not torch.equal(a, b):
+                        raise AssertionError("job %r differs from the one-workspace result" % (jobs[i],))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    kl.set_workspace_slots(4)
+    try:
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        kl.set_workspace_slots(1)
+    assert not errors, errors
+    # what the extra workspaces held is released with the rest, and the library comes back
+    assert kl.library().kyber_hip_release() == 0
+    got = runs[1]()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want[1]))
