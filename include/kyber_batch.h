@@ -305,12 +305,15 @@ void kyber_hip_host_free(void *p);
 int kyber_hip_set_chunk(size_t instances);
 /* Workspaces per device, 1 (the default) to 8.  No counterpart in the reference, whose calls
  * share nothing.  With one workspace the GPU work of any two pipeline calls on a device is
- * ordered, whatever streams they are queued on.  With s > 1, device-pointer calls of up to
- * 65 536 instances that arrive on different streams (e.g. from the request threads of a
- * server) take different workspaces and run side by side on the device, which such batches
- * leave mostly idle; calls on one stream, larger batches and calls under stream capture
- * behave as before.  Each extra workspace is sized by the largest batch it has served
- * (about 5.7 KB per Kyber768 instance).  Takes effect for the calls that start after it. */
+ * ordered, whatever streams they are queued on.  With s > 1, calls of up to 65 536 instances
+ * that arrive on different streams, or through the host-pointer entry points from different
+ * threads (e.g. the request threads of a server), take different workspaces and run side by
+ * side on the device, which such batches leave mostly idle.  In this mode no call uses the
+ * library's second stream and a workspace that changes hands between streams is waited for on
+ * the host, so no stream ever waits on the device for another.  Calls on one stream, larger
+ * batches and calls under stream capture behave as before.  Each extra workspace is sized by
+ * the largest batch it has served (about 5.7 KB per Kyber768 instance).  Takes effect for the
+ * calls that start after it; use at least as many slots as there are calling threads. */
 int kyber_hip_set_workspace_slots(int slots);
 /* Tuning/test aid (no counterpart in the reference): upper bound on the records
  * of the matrix sampler's tail queue per pass.  Entries that do not fit are

@@ -18,6 +18,7 @@
 #include <strings.h>
 #include <sys/random.h>
 #include <unistd.h>
+#include <pthread.h>
 
 #include "../../include/kyber_batch.h"
 #include "../../include/kyber_api.h"
@@ -31,6 +32,8 @@ using namespace ky;
 namespace {
 
 thread_local char g_err[256] = "";
+static const bool g_trace = getenv("KYBER_HIP_TRACE") != nullptr;
+#define TR(...) do { if (g_trace) { fprintf(stderr, "[ky %lx] ", (unsigned long)pthread_self()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 int hip_fail(hipError_t e, const char* what) {
   snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -84,14 +87,17 @@ int ws_reserve(int slot, size_t bytes, uint8_t** out) {
   if (dev < 0 || dev >= MAX_DEV || slot < 0 || slot >= MAX_SLOTS) return KYBER_HIP_EINVAL;
   Workspace& w = g_ws[dev][slot];
   if (w.bytes < bytes) {
+    TR("ws_reserve slot %d grow %zu -> %zu", slot, w.bytes, bytes);
     if (w.base) {
       HIP_TRY(hipDeviceSynchronize());
+      TR("ws_reserve synced");
       HIP_TRY(hipFree(w.base));
       w.base = nullptr;
       w.bytes = 0;
     }
     HIP_TRY(hipMalloc(&w.base, bytes));
     w.bytes = bytes;
+    TR("ws_reserve done");
   }
   *out = static_cast<uint8_t*>(w.base);
   return 0;
@@ -141,21 +147,37 @@ struct WsUse {
     if (e != hipSuccess) { rc = hip_fail(e, "hipGetDevice"); return; }
     if (dev < 0 || dev >= MAX_DEV) { rc = KYBER_HIP_EINVAL; return; }
     const int nslot = g_slots.load();
-    if (nslot > 1 && n <= POOL_MAX_N && !stream_capturing(st)) slot = pick_slot(dev, nslot, st);
+    const bool pool = nslot > 1 && !stream_capturing(st);
+    if (pool && n <= POOL_MAX_N) slot = pick_slot(dev, nslot, st);
     Workspace* ws = &g_ws[dev][slot];
+    TR("WsUse n %zu st %p slot %d used %d last %p", n, (void*)st, slot, (int)ws->used, (void*)ws->last);
     if (!ws->idle && (e = hipEventCreateWithFlags(&ws->idle, hipEventDisableTiming)) != hipSuccess) {
       ws->idle = nullptr;
       rc = hip_fail(e, "hipEventCreateWithFlags");
       return;
     }
-    // an unordered second user of the one workspace would corrupt both calls: fail instead
-    if (ws->used && ws->last != st && (e = hipStreamWaitEvent(st, ws->idle, 0)) != hipSuccess) {
-      rc = hip_fail(e, "hipStreamWaitEvent");
-      return;
+    // an unordered second user of the one workspace would corrupt both calls: fail instead.
+    // With several workspaces the HOST waits for the workspace's last call (normally finished long ago: pick_slot
+    // prefers such a slot) and no stream ever waits on the device for another: a stream that does holds up its
+    // hardware queue, which other callers' streams share.  (The standstill met while this mode was built -- 8
+    // streams on 4 workspaces, two of them never drained -- went away with the second stream, see side_for; the
+    // host-side wait is the cautious half of the same rule.)
+    if (ws->used && ws->last != st) {
+      if (pool) {
+        TR("WsUse host wait");
+        if ((e = hipEventSynchronize(ws->idle)) != hipSuccess) {
+          rc = hip_fail(e, "hipEventSynchronize");
+          return;
+        }
+      } else if ((e = hipStreamWaitEvent(st, ws->idle, 0)) != hipSuccess) {
+        rc = hip_fail(e, "hipStreamWaitEvent");
+        return;
+      }
     }
     w = ws;
   }
   ~WsUse() {
+    TR("~WsUse slot %d", slot);
     if (!w) return;
     if (hipEventRecord(w->idle, st) != hipSuccess) {
       // the next call cannot be ordered behind this one on the device: order it on the host
@@ -267,6 +289,7 @@ inline void prof_end(const char* name, hipStream_t st, hipEvent_t a) {
 }
 #define RUN(name, st, ...)        \
   do {                            \
+    TR("run %s", name);           \
     hipEvent_t ev_a_{};           \
     prof_begin(st, &ev_a_);       \
     __VA_ARGS__;                  \
@@ -360,6 +383,11 @@ Side g_side[MAX_DEV][MAX_SLOTS];  // one per workspace, under g_dev_mu like it
 
 Side* side_for(size_t n, hipStream_t st, int slot) {
   if (n > SIDE_MAX_N) return nullptr;
+  // Several workspaces: calls overlap with each other, which fills the device better than a call's own second
+  // stream -- and the fork/join of that stream between several streams that are busy at once stalled two of them
+  // for good (tools/slots_stress.py 4 25 0 1 2 7 4 with the second stream; without it every mix runs).  One stream
+  // per call there, as in the no-allocation entry point.
+  if (g_slots.load() > 1) return nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
@@ -389,6 +417,7 @@ Side* side_for(size_t n, hipStream_t st, int slot) {
 }
 // everything queued on st so far (the previous user of the workspace included) comes first
 int side_begin(Side* sd, hipStream_t st) {
+  TR("side_begin");
   HIP_TRY(hipEventRecord(sd->fork, st));
   HIP_TRY(hipStreamWaitEvent(sd->s, sd->fork, 0));
   return 0;
@@ -398,6 +427,7 @@ int side_end(Side* sd) {
   return 0;
 }
 int side_join(Side* sd, hipStream_t st) {
+  TR("side_join");
   HIP_TRY(hipStreamWaitEvent(st, sd->join, 0));
   return 0;
 }
@@ -1032,8 +1062,11 @@ struct Streams {
 };
 
 // Streams, events and the staging allocation are kept per device between calls
-// (small batches would otherwise spend most of their time creating them); host
-// calls on one device are serialised by that device's g_host_mu entry.
+// (small batches would otherwise spend most of their time creating them).  One context per
+// device by default, whose lock serialises the host calls on that device; with
+// kyber_hip_set_workspace_slots(s > 1) there are s, and a host call of up to POOL_MAX_N instances
+// takes one that is free (HostLock), so calls from several threads overlap: each context has its own
+// streams, and a stream keeps to its workspace (pick_slot).
 struct HostCtx {
   Streams S;
   uint8_t* staging = nullptr;
@@ -1041,22 +1074,46 @@ struct HostCtx {
   uint8_t* mirror = nullptr;  // pinned host copy of the staging area's layout, for small batches (host_pipeline)
 };
 constexpr size_t HOST_MIRROR_BYTES = 1u << 20;  // Kyber768: up to n = 256 (the CPU moves these bytes, as the runtime would for pageable memory)
-HostCtx* g_host[MAX_DEV] = {};
-std::mutex g_host_mu[MAX_DEV];
+HostCtx* g_host[MAX_DEV][MAX_SLOTS] = {};
+std::mutex g_host_mu[MAX_DEV][MAX_SLOTS];
+std::atomic<unsigned> g_host_rr[MAX_DEV];
 
-int host_ctx(size_t bytes, HostCtx** out) {
+// holds one of the current device's host contexts for the length of a host-pointer call
+struct HostLock {
+  int dev = 0, idx = 0;
+  std::unique_lock<std::mutex> lk;
+  explicit HostLock(size_t n) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    const int nslot = g_slots.load();
+    if (nslot > 1 && n <= POOL_MAX_N) {
+      for (int i = 0; i < nslot; i++) {
+        std::unique_lock<std::mutex> t(g_host_mu[dev][i], std::try_to_lock);
+        if (t.owns_lock()) {
+          idx = i;
+          lk = std::move(t);
+          return;
+        }
+      }
+      idx = (int)(g_host_rr[dev]++ % (unsigned)nslot);  // all busy: queue behind one of them
+    }
+    lk = std::unique_lock<std::mutex>(g_host_mu[dev][idx]);
+  }
+};
+
+int host_ctx(const HostLock& hl, size_t bytes, HostCtx** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= MAX_DEV) return KYBER_HIP_EINVAL;
-  if (!g_host[dev]) {
+  if (dev != hl.dev) return KYBER_HIP_EINVAL;
+  if (!g_host[dev][hl.idx]) {
     HostCtx* c = new HostCtx();
     if (int rc = c->S.init()) {
       delete c;
       return rc;
     }
-    g_host[dev] = c;
+    g_host[dev][hl.idx] = c;
   }
-  HostCtx* c = g_host[dev];
+  HostCtx* c = g_host[dev][hl.idx];
   if (c->cap < bytes) {
     if (c->staging) {
       HIP_TRY(hipDeviceSynchronize());
@@ -1074,7 +1131,7 @@ int host_ctx(size_t bytes, HostCtx** out) {
 // f(m, in[], out[], stream): the device-pointer routine for one pass of m instances
 template <class F>
 int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer_list<HostOut> outs_, F&& f) {
-  std::lock_guard<std::mutex> hlk(dev_mutex(g_host_mu));
+  HostLock hlk(n);
   const std::vector<HostIn> ins(ins_);
   const std::vector<HostOut> outs(outs_);
   const size_t pass = n < HOST_PASS ? n : HOST_PASS;
@@ -1085,7 +1142,7 @@ int host_pipeline(size_t n, std::initializer_list<HostIn> ins_, std::initializer
   for (auto& a : ins) total += a.once ? pad(a.per) : slots * pad(a.per * pass);
   for (auto& a : outs) total += slots * pad(a.per * pass);
   HostCtx* ctx = nullptr;
-  if (int rc = host_ctx(total, &ctx)) return rc;
+  if (int rc = host_ctx(hlk, total, &ctx)) return rc;
   Streams& S = ctx->S;
   // A batch that fits one pass has nothing to overlap: copies and kernels go down ONE stream in order,
   // which saves the two cross-stream event hops and two stream synchronisations of the general path
@@ -1938,10 +1995,11 @@ int kyber_hip_set_tail_capacity(size_t records) {
 // every device the library holds something on: workspace, host-path staging and streams, and the
 // contents of the no-allocation scratch array (the array itself is part of the code object)
 static int release_device(int dev) {
-  std::lock_guard<std::mutex> hlk(g_host_mu[dev]);  // same order as the host-pointer calls: host lock, then workspace lock
+  std::unique_lock<std::mutex> hlk[MAX_SLOTS];  // same order as the host-pointer calls: host lock(s), then workspace lock
+  for (int s = 0; s < MAX_SLOTS; s++) hlk[s] = std::unique_lock<std::mutex>(g_host_mu[dev][s]);
   std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
-  bool any = g_host[dev] || g_scratch_ptr[dev];
-  for (int s = 0; s < MAX_SLOTS; s++) any = any || g_ws[dev][s].base || g_ws[dev][s].idle || g_side[dev][s].s;
+  bool any = g_scratch_ptr[dev] != nullptr;
+  for (int s = 0; s < MAX_SLOTS; s++) any = any || g_host[dev][s] || g_ws[dev][s].base || g_ws[dev][s].idle || g_side[dev][s].s;
   if (!any) return 0;
   HIP_TRY(hipSetDevice(dev));
   HIP_TRY(hipDeviceSynchronize());
@@ -1961,17 +2019,21 @@ static int release_device(int dev) {
     if (w.idle) (void)hipEventDestroy(w.idle);
     w = Workspace{};
   }
-  if (HostCtx* c = g_host[dev]) {
+  for (int s = 0; s < MAX_SLOTS; s++) {
+    HostCtx* c = g_host[dev][s];
+    if (!c) continue;
     if (c->staging) {
       HIP_TRY(hipMemset(c->staging, 0, c->cap));  // secret keys and shared secrets were staged here
       HIP_TRY(hipFree(c->staging));
+      c->staging = nullptr;
+      c->cap = 0;
     }
     if (c->mirror) {  // wiped after every call (host_pipeline)
       HIP_TRY(hipHostFree(c->mirror));
       c->mirror = nullptr;
     }
     delete c;  // streams and events
-    g_host[dev] = nullptr;
+    g_host[dev][s] = nullptr;
   }
   if (g_scratch_ptr[dev]) {
     HIP_TRY(hipMemset(g_scratch_ptr[dev], 0, NOALLOC_SCRATCH_BYTES));  // m', r', Kbar', PRF bytes of the last no-allocation call

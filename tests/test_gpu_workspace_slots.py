@@ -1,7 +1,7 @@
 """GPU: kyber_hip_set_workspace_slots (include/kyber_batch.h).  With several workspaces per device, small batches
 that arrive on different streams from different host threads overlap on the device; every byte must be what the
 one-workspace library gives (itself pinned by the oracle, the vectors and the soak), for the SHAKE sets, a 90s
-set (its second stream is per workspace), ML-KEM, and with a large batch (always slot 0) in the mix."""
+set (whose second stream stays unused in this mode: tools/slots_stress.py), ML-KEM, and with a large batch (always slot 0) in the mix."""
 import threading
 
 import numpy as np
@@ -86,3 +86,46 @@ def test_concurrent_streams_on_several_workspaces_give_the_same_bytes(oracle):
     got = runs[1]()
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(got, want[1]))
+
+
+def test_host_pointer_calls_from_threads_on_several_contexts(oracle):
+    """Host-pointer calls (the reference-shaped API of a multithreaded caller): with several slots each takes a free
+    host context (own streams and staging) and they overlap; outputs against the oracle."""
+    k = 3
+    kem = kyber_amd.KyberHip(k)
+    sizes = [1, 1, 7, 200, 1000, 40000]
+    data = []
+    for i, n in enumerate(sizes):
+        rng = np.random.default_rng(500 + i)
+        kc, ec = rng.integers(0, 256, (n, 64), dtype=np.uint8), rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pk, sk = oracle.keypair(k, kc)
+        ct, ss = oracle.enc(k, pk, ec)
+        data.append((kc, ec, pk, sk, ct, ss))
+    errors = []
+
+    def worker(i):
+        try:
+            kc, ec, pk, sk, ct, ss = data[i]
+            for _ in range(4 if sizes[i] > 10000 else 20):
+                gpk, gsk = kem.keypair(kc)
+                gct, gss = kem.enc(gpk, ec)
+                gdec = kem.dec(gct, gsk)
+                if not (np.array_equal(gpk, pk) and np.array_equal(gsk, sk) and np.array_equal(gct, ct)
+                        and np.array_equal(gss, ss) and np.array_equal(gdec, ss)):
+                    raise AssertionError("host-pointer job %d (n = %d) differs from the oracle" % (i, sizes[i]))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    kl.set_workspace_slots(4)
+    try:
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(sizes))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        kl.set_workspace_slots(1)
+    assert not errors, errors
+    assert kl.library().kyber_hip_release() == 0
+    gpk, gsk = kem.keypair(data[3][0])
+    assert np.array_equal(gpk, data[3][2]) and np.array_equal(gsk, data[3][3])

@@ -58,6 +58,57 @@ def measure(threads, n, op):
     return threads * CALLS / dt
 
 
+import numpy as np  # noqa: E402
+
+hp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+
+def measure_host(threads, n, op):
+    """the same with host pointers (pageable memory): what a multithreaded caller of the reference-shaped API does"""
+    ctx = []
+    for t in range(threads):
+        rng = np.random.default_rng(1000 * t + n)
+        kc, ec = rng.integers(0, 256, (n, 64), dtype=np.uint8), rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pk, sk = kem.keypair(kc)
+        ct, ss = kem.enc(pk, ec)
+        ctx.append((pk, sk, ct, ss, ec, np.empty_like(ss), np.empty_like(ct)))
+    bar = threading.Barrier(threads + 1)
+
+    def worker(t):
+        pk, sk, ct, ss, ec, ss2, ct2 = ctx[t]
+        bar.wait()
+        for _ in range(CALLS):
+            if op == "dec":
+                assert L.kyber_batch_dec(K, 0, n, hp(ss2), hp(ct), hp(sk)) == 0
+            else:
+                assert L.kyber_batch_enc(K, 0, n, hp(ct2), hp(ss2), hp(pk), hp(ec)) == 0
+        assert np.array_equal(ss2, ss)
+        bar.wait()
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for t in ths:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    dt = time.perf_counter() - t0
+    for t in ths:
+        t.join()
+    return threads * CALLS / dt
+
+
+for op in ("enc", "dec"):
+    for n in (1, 256):
+        row = []
+        for threads in (1, 2, 4, 8):
+            kl.set_workspace_slots(1)
+            a = measure_host(threads, n, op)
+            kl.set_workspace_slots(min(threads, 8))
+            b = measure_host(threads, n, op)
+            kl.set_workspace_slots(1)
+            row.append("%d thr %6.0f -> %6.0f" % (threads, a, b))
+        print("%s n=%5d  host pointers, calls/s, 1 workspace -> one per thread:  " % (op, n) + " | ".join(row), flush=True)
+
 for op in ("enc", "dec"):
     for n in (1, 256, 4096, 16384):
         row = []
