@@ -40,6 +40,17 @@ def _job(kind, k, n90, n, seed):
     return run
 
 
+def _join_all(threads, seconds=150):
+    """A stream that never drains (what tools/slots_stress.py found while this mode was built) must fail the test, not hang it."""
+    import time
+    deadline = time.time() + seconds
+    for t in threads:
+        t.join(max(0.0, deadline - time.time()))
+    stuck = [t.name for t in threads if t.is_alive()]
+    if stuck:
+        pytest.fail("threads %r still waiting for their streams after %d s" % (stuck, seconds), pytrace=False)
+
+
 def test_slots_argument_range():
     L = kl.library()
     assert L.kyber_hip_set_workspace_slots(0) == -1 and L.kyber_hip_set_workspace_slots(9) == -1
@@ -73,11 +84,10 @@ def test_concurrent_streams_on_several_workspaces_give_the_same_bytes(oracle):
 
     kl.set_workspace_slots(4)
     try:
-        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+        ths = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(len(jobs))]
         for t in ths:
             t.start()
-        for t in ths:
-            t.join()
+        _join_all(ths)
     finally:
         kl.set_workspace_slots(1)
     assert not errors, errors
@@ -118,11 +128,10 @@ def test_host_pointer_calls_from_threads_on_several_contexts(oracle):
 
     kl.set_workspace_slots(4)
     try:
-        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(sizes))]
+        ths = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(len(sizes))]
         for t in ths:
             t.start()
-        for t in ths:
-            t.join()
+        _join_all(ths)
     finally:
         kl.set_workspace_slots(1)
     assert not errors, errors
