@@ -310,8 +310,9 @@ int kyber_hip_set_chunk(size_t instances);
  * threads (e.g. the request threads of a server), take different workspaces and run side by
  * side on the device, which such batches leave mostly idle.  In this mode no call uses the
  * library's second stream and a workspace that changes hands between streams is waited for on
- * the host, so no stream ever waits on the device for another.  Calls on one stream, larger
- * batches and calls under stream capture behave as before.  Each extra workspace is sized by
+ * the host, so no stream ever waits on the device for another.  Calls on one stream and larger
+ * batches behave as before; a call under stream capture takes the workspace that a call of its
+ * size outside capture laid out last (it cannot allocate), whichever that is.  Each extra workspace is sized by
  * the largest batch it has served (about 5.7 KB per Kyber768 instance).  Takes effect for the
  * calls that start after it; use at least as many slots as there are calling threads. */
 int kyber_hip_set_workspace_slots(int slots);

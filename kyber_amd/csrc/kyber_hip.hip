@@ -61,8 +61,8 @@ struct Workspace {
 // streams take different workspaces, so their kernels overlap on the device -- small batches leave most of it
 // idle ("small batches") and a server with several request threads wants them side by side.
 // Every workspace on its own keeps the one-workspace protocol, so the choice of slot is a matter of speed only.
-// Larger batches fill the chip alone and calls under stream capture must find the memory a call outside
-// capture laid out: both always take slot 0.
+// Larger batches fill the chip alone and always take slot 0; a call under stream capture takes the workspace
+// a call outside capture laid out for its size (WsUse).
 constexpr int MAX_SLOTS = 8;
 constexpr size_t POOL_MAX_N = 65536;
 Workspace g_ws[MAX_DEV][MAX_SLOTS];
@@ -142,13 +142,30 @@ struct WsUse {
   int slot = 0;
   int dev = 0;
   int rc = 0;  // checked by the caller before it launches anything
-  WsUse(hipStream_t s, size_t n) : st(s) {
+  bool passive = false;  // a captured call among several workspaces: takes one, leaves no trace in its state
+  // need: the bytes the call will ask ws_reserve for
+  WsUse(hipStream_t s, size_t n, size_t need) : st(s) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) { rc = hip_fail(e, "hipGetDevice"); return; }
     if (dev < 0 || dev >= MAX_DEV) { rc = KYBER_HIP_EINVAL; return; }
     const int nslot = g_slots.load();
-    const bool pool = nslot > 1 && !stream_capturing(st);
+    const bool capturing = nslot > 1 && stream_capturing(st);
+    const bool pool = nslot > 1 && !capturing;
     if (pool && n <= POOL_MAX_N) slot = pick_slot(dev, nslot, st);
+    if (capturing) {
+      // A captured call cannot allocate, so it takes the workspace that is large enough and was used last (the one
+      // a call of this size outside capture laid out), else slot 0 as with one workspace.  What it records runs at
+      // replay time only: there is nothing to wait for now and nothing for later calls to wait for, and the caller
+      // orders replays against other calls, as the header says.
+      int best = -1;
+      for (int i = 0; i < nslot; i++)
+        if (g_ws[dev][i].bytes >= need && (best < 0 || g_ws[dev][i].stamp > g_ws[dev][best].stamp)) best = i;
+      if (best >= 0) slot = best;
+      TR("WsUse n %zu st %p slot %d (captured)", n, (void*)st, slot);
+      w = &g_ws[dev][slot];
+      passive = true;
+      return;
+    }
     Workspace* ws = &g_ws[dev][slot];
     TR("WsUse n %zu st %p slot %d used %d last %p", n, (void*)st, slot, (int)ws->used, (void*)ws->last);
     if (!ws->idle && (e = hipEventCreateWithFlags(&ws->idle, hipEventDisableTiming)) != hipSuccess) {
@@ -178,7 +195,7 @@ struct WsUse {
   }
   ~WsUse() {
     TR("~WsUse slot %d", slot);
-    if (!w) return;
+    if (!w || passive) return;
     if (hipEventRecord(w->idle, st) != hipSuccess) {
       // the next call cannot be ordered behind this one on the device: order it on the host
       (void)hipStreamSynchronize(st);
@@ -454,10 +471,10 @@ int expand_matrix_beside(Side* sd, bool* pending, int insts, const uint8_t* rho,
 template <class P, bool N90>
 int keypair_dev(size_t n, uint8_t* pk, uint8_t* sk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
@@ -495,10 +512,10 @@ template <class P, bool N90>
 int enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* pk, size_t pk_stride, const uint8_t* coins, hipStream_t st,
             const int16_t* pmat = nullptr, const uint8_t* phpk = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   const bool shared = pk_stride == 0;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
@@ -615,10 +632,10 @@ int dec_run(size_t n, size_t chunk, Layout<P>& L, uint8_t* ss, const uint8_t* ct
 template <class P, bool N90>
 int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t sk_stride, hipStream_t st, const int16_t* pmat = nullptr) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
   return dec_run<P, N90>(n, chunk, L, ss, ct, sk, sk_stride, st, pmat, sk_stride == 0 ? side_for(n, st, use.slot) : nullptr);
@@ -628,10 +645,10 @@ int dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* sk, size_t 
 template <class P>
 int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
@@ -654,10 +671,10 @@ int ml_keypair_dev(size_t n, uint8_t* ek, uint8_t* dk, const uint8_t* coins, hip
 template <class P>
 int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint8_t* coins, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {
@@ -683,10 +700,10 @@ int ml_enc_dev(size_t n, uint8_t* ct, uint8_t* ss, const uint8_t* ek, const uint
 template <class P>
 int ml_dec_dev(size_t n, uint8_t* ss, const uint8_t* ct, const uint8_t* dk, hipStream_t st) {
   std::lock_guard<std::mutex> lk(dev_mutex(g_dev_mu));
-  WsUse use(st, n);
-  if (use.rc) return use.rc;
   const size_t gc = g_chunk.load();
   const size_t chunk = n < gc ? n : gc;
+  WsUse use(st, n, Layout<P>::need(chunk));
+  if (use.rc) return use.rc;
   Layout<P> L;
   if (int rc = L.carve(chunk, use)) return rc;
   for (size_t o = 0; o < n; o += chunk) {

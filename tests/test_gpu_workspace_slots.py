@@ -138,3 +138,46 @@ def test_host_pointer_calls_from_threads_on_several_contexts(oracle):
     assert kl.library().kyber_hip_release() == 0
     gpk, gsk = kem.keypair(data[3][0])
     assert np.array_equal(gpk, data[3][2]) and np.array_equal(gsk, data[3][3])
+
+
+def test_captured_calls_among_several_workspaces(oracle):
+    """Stream capture with several workspaces configured: the captured call finds the workspace that an eager call of
+    its size laid out -- whichever slot that was -- and replays with the oracle's bytes; eager calls on other streams
+    in between (the caller orders them against the replays, here by synchronising)."""
+    k, n = 3, 100
+    kem = kyber_amd.KyberHip(k)
+    rng = np.random.default_rng(99)
+    kc, ec = rng.integers(0, 256, (n, 64), dtype=np.uint8), rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    opk, osk = oracle.keypair(k, kc)
+    oct_, oss = oracle.enc(k, opk, ec)
+    pk, sk, dec = (torch.from_numpy(a).cuda() for a in (opk, osk, ec))
+    kl.set_workspace_slots(4)
+    try:
+        busy = torch.cuda.Stream()
+        with torch.cuda.stream(busy):          # takes the first slot, with a smaller batch
+            kem.enc_dev(pk[:3].contiguous(), dec[:3].contiguous())
+        warm = torch.cuda.Stream()
+        with torch.cuda.stream(warm):          # lays out another slot for n
+            kem.dec_dev(kem.enc_dev(pk, dec)[0], sk)
+        torch.cuda.synchronize()
+        ct, ss, ssd = (torch.zeros((n, kem.ct_bytes), dtype=torch.uint8, device="cuda"), torch.zeros((n, 32), dtype=torch.uint8, device="cuda"),
+                       torch.zeros((n, 32), dtype=torch.uint8, device="cuda"))
+        cap, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(graph, stream=cap):
+                kem.enc_dev(pk, dec, ct, ss)
+                kem.dec_dev(ct, sk, ssd)
+        torch.cuda.synchronize()
+        assert not bool(ss.any())
+        for _ in range(3):
+            ct.zero_(), ss.zero_(), ssd.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(ct.cpu().numpy(), oct_) and np.array_equal(ss.cpu().numpy(), oss) and np.array_equal(ssd.cpu().numpy(), oss)
+            with torch.cuda.stream(busy):
+                c2, s2 = kem.enc_dev(pk, dec)
+            torch.cuda.synchronize()
+            assert np.array_equal(c2.cpu().numpy(), oct_) and np.array_equal(s2.cpu().numpy(), oss)
+    finally:
+        kl.set_workspace_slots(1)
