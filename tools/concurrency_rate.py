@@ -58,6 +58,13 @@ def measure(threads, n, op):
     return threads * CALLS / dt
 
 
+if len(sys.argv) > 1:  # tools/concurrency_rate.py <threads> <n> <enc|dec> <slots>: one measurement (e.g. under rocprofv3 --kernel-trace)
+    T, N, OP, S = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    kl.set_workspace_slots(S)
+    print("%s n=%d, %d threads, %d workspaces: %.0f calls/s" % (OP, N, T, S, measure(T, N, OP)), flush=True)
+    kl.set_workspace_slots(1)
+    sys.exit(0)
+
 import numpy as np  # noqa: E402
 
 hp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
