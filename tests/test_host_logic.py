@@ -151,6 +151,8 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.kyber_hip_set_chunk((1 << 24) + 1) == -1
     assert lib.kyber_hip_set_chunk(0) == 0
     assert lib.kyber_hip_set_tail_capacity((1 << 64) - 1) == 0
+    assert lib.kyber_hip_set_workspace_slots(0) == -1 and lib.kyber_hip_set_workspace_slots(9) == -1
+    assert lib.kyber_hip_set_workspace_slots(8) == 0 and lib.kyber_hip_set_workspace_slots(1) == 0
 
 
 def test_16bit_montgomery_forms_match_reference_reduce(oracle):
