@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Latency of small ML-KEM-768 batches (include/mlkem_batch.h): microseconds per call, median of 200,
+"""Latency of small ML-KEM batches (include/mlkem_batch.h), tools/latency_mlkem.py [k = 3]: ML-KEM-512/768/1024
+for k = 2/3/4; microseconds per call, median of 200,
 host pointers and device pointers (enqueue + synchronise of the caller's stream).
 KY_LAT_SIZES=1,256,...: other sizes."""
 import ctypes
@@ -15,7 +16,8 @@ import kyber_amd  # noqa: E402
 from kyber_amd import lib as kl  # noqa: E402
 
 L = kl.library()
-K = 3
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+print("ML-KEM-%d" % (256 * K), flush=True)
 ml = kyber_amd.MlKemHip(K)
 p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 d = lambda t: ctypes.c_void_p(t.data_ptr())
